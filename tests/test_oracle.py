@@ -1,0 +1,206 @@
+"""CPU tests: the oracle (oracle/d2pc_oracle.c) against the exact-rational
+known-answer vectors in tests/golden/ and against closed forms.
+
+The reference has no tests; these are the T0/T1 tiers of SURVEY.md section 4.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import assert_points_close, ulp_distance, synth_disparity
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "reproject_exact.npz"))
+
+
+def _case(golden, name):
+    q = golden[name + "__q"]
+    border = int(golden[name + "__border"])
+    exp = golden[name + "__expected_bits"].view(np.float32)
+    return q, border, exp
+
+
+def test_make_q_default_matches_survey_constants():
+    # SURVEY.md section 8 row a9 / hpp:66-71,84-104
+    q = oracle.make_q()
+    assert q[0] == 1 and q[5] == 1 and q[1] == 0 and q[2] == 0
+    assert abs(q[3] - (-375.999481966846)) < 1e-9
+    assert q[7] == -240.0
+    assert q[11] == 713.5
+    assert abs(q[14] - 1 / 0.09) < 1e-12
+    assert q[15] == 0.0 and np.signbit(q[15]), "Q[3][3] must be negative zero"
+    assert q[10] == 0 and q[12] == 0 and q[13] == 0
+
+
+@pytest.mark.parametrize("form", [oracle.FORM_CV24, oracle.FORM_CV4])
+@pytest.mark.parametrize("name", ["A_default_q_k8", "B_dense_q", "C_extremes"])
+def test_oracle_vs_exact_rational(golden, name, form):
+    q, border, exp = _case(golden, name)
+    disp = golden[name + "__disp"]
+    got = oracle.reproject(disp, q, border=border, form=form)
+    # a double evaluation + one cast is within 1 ulp of the correctly rounded
+    # exact value; the OpenCV-4 form casts twice => 2 ulp
+    assert_points_close(got, exp, max_ulp=1 if form == oracle.FORM_CV24 else 2, what=name)
+    exact_frac = (ulp_distance(got[:, :3], exp[:, :3]) == 0).mean()
+    assert exact_frac > (0.99 if form == oracle.FORM_CV24 else 0.5), exact_frac
+
+
+def test_oracle_u8_decode_centre_rows(golden):
+    name = "D_centre_rows_u8"
+    q, border, exp = _case(golden, name)
+    r0, r1 = golden[name + "__rows"]
+    rows = golden[name + "__raw_u8_rows"]
+    raw = np.ones((r1, rows.shape[1]), dtype=np.uint8)
+    raw[r0:r1] = rows
+    got = oracle.reproject(raw, q, border=0, scale=0.125)
+    w = raw.shape[1]
+    sub = got[r0 * w : r1 * w]
+    assert_points_close(sub, exp, max_ulp=1, what=name)
+    # the same frame pre-decoded on the host, as the reference does (cpp:60-61)
+    got_f = oracle.reproject(raw.astype(np.float32) * np.float32(0.125), q, border=0)
+    assert np.array_equal(got.view(np.uint32), got_f.view(np.uint32))
+    # Y is exactly +0 on row v = 240 (cy' = 240)
+    y240 = got[240 * w : 241 * w, 1]
+    assert np.all(y240 == 0) and not np.signbit(y240).any()
+
+
+def test_default_q_closed_form():
+    # Z = f'*b/d = 64.215/d, X = (u-cx')*b/d, Y = (v-240)*b/d
+    q = oracle.make_q()
+    disp = synth_disparity(2, 0, 752, 480, "k8")
+    pts = oracle.reproject(disp, q, border=40)
+    assert pts.shape == (672 * 400, 4)
+    v, u = np.mgrid[40:440, 40:712]
+    d = disp[40:440, 40:712].astype(np.float64)
+    z = 713.5 * 0.09 / d
+    x = (u - 375.999481966846) * 0.09 / d
+    y = (v - 240.0) * 0.09 / d
+    ref = np.stack([x, y, z], axis=-1).reshape(-1, 3)
+    err = np.abs(pts[:, :3] - ref) / np.maximum(np.abs(ref), 1e-30)
+    assert err[ref != 0].max() < 5e-7
+    assert np.all(pts[:, 3].view(np.uint32) == 0x3F800000)
+
+
+def test_zero_disparity_inf_nan_pattern():
+    # d = 0 with the default Q => W = +0, iW = +inf,
+    # X = sign(u-cx')*inf, Y = sign(v-240)*inf (NaN on v = 240), Z = +inf.
+    q = oracle.make_q()
+    disp = np.zeros((330, 752), dtype=np.float32)
+    for form in (oracle.FORM_CV24, oracle.FORM_CV4):
+        pts = oracle.reproject(disp, q, border=40, form=form).reshape(250, 672, 4)
+        v, u = np.mgrid[40:290, 40:712]
+        assert np.all(np.isposinf(pts[..., 2]))
+        assert np.array_equal(np.isposinf(pts[..., 0]), u > 375.9995)
+        assert np.array_equal(np.isneginf(pts[..., 0]), u < 375.9995)
+        assert np.array_equal(np.isnan(pts[..., 1]), v == 240)
+        assert np.array_equal(np.isposinf(pts[..., 1]), v > 240)
+        assert np.array_equal(np.isneginf(pts[..., 1]), v < 240)
+
+
+def test_forms_agree_within_2ulp():
+    rng = np.random.default_rng(7)
+    q = rng.uniform(-1, 1, 16)
+    q[12:16] = [2e-4, 1e-4, 0.03, 0.7]
+    disp = rng.uniform(0.5, 128, size=(97, 131)).astype(np.float32)
+    a = oracle.reproject(disp, q, border=5, form=oracle.FORM_CV24)
+    b = oracle.reproject(disp, q, border=5, form=oracle.FORM_CV4)
+    assert_points_close(a, b, max_ulp=2)
+
+
+def test_roi_geometry_and_index_map():
+    # cpp:70-76: 96x96 frame, border 40 -> 16x16 points, i = (v-40)*16 + (u-40)
+    q = np.eye(4).reshape(16)  # identity: point = (u, v, d)
+    disp = np.arange(96 * 96, dtype=np.float32).reshape(96, 96) / 4 + 1
+    pts = oracle.reproject(disp, q, border=40)
+    assert pts.shape == (256, 4)
+    v, u = np.mgrid[40:56, 40:56]
+    assert np.array_equal(pts[:, 0], u.reshape(-1).astype(np.float32))
+    assert np.array_equal(pts[:, 1], v.reshape(-1).astype(np.float32))
+    assert np.array_equal(pts[:, 2], disp[40:56, 40:56].reshape(-1))
+    cpts, idx = oracle.reproject_compact(disp, q, border=40)
+    assert np.array_equal(cpts, pts)
+    assert np.array_equal(idx, (v * 96 + u).reshape(-1).astype(np.uint32))
+
+
+@pytest.mark.parametrize("w,h", [(80, 80), (80, 200), (200, 80), (79, 300), (1, 1), (81, 81)])
+def test_degenerate_sizes(w, h):
+    # cpp:70,72: loops are empty when a dimension is <= 2*border
+    q = oracle.make_q()
+    disp = np.ones((h, w), dtype=np.float32)
+    pts = oracle.reproject(disp, q, border=40)
+    assert pts.shape[0] == max(w - 80, 0) * max(h - 80, 0)
+
+
+def test_row_stride_is_honoured():
+    q = oracle.make_q()
+    big = synth_disparity(2, 1, 200, 100, "k8")
+    view = big[:, :150]  # 150 px rows with a 200 px stride
+    a = oracle.reproject(view, q, border=10)
+    b = oracle.reproject(np.ascontiguousarray(view), q, border=10)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_threads_are_bit_identical():
+    q = oracle.make_q()
+    disp = synth_disparity(4, 0, 640, 480, "holes")
+    a = oracle.reproject(disp, q, border=40, threads=1)
+    b = oracle.reproject(disp, q, border=40, threads=4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_compact_is_filter_of_parity():
+    q = oracle.make_q()
+    disp = synth_disparity(3, 0, 320, 240, "holes")
+    full = oracle.reproject(disp, q, border=40)
+    cpts, idx = oracle.reproject_compact(disp, q, border=40)
+    keep = np.isfinite(full[:, :3]).all(axis=1)
+    assert 0.6 < keep.mean() < 0.8
+    assert np.array_equal(cpts.view(np.uint32), full[keep].view(np.uint32))
+    v, u = np.mgrid[40:200, 40:280]
+    assert np.array_equal(idx, (v * 320 + u).reshape(-1)[keep].astype(np.uint32))
+    assert np.all(np.diff(idx.astype(np.int64)) > 0)
+    # min_disparity predicate: !(d <= t)
+    cpts2, idx2 = oracle.reproject_compact(disp, q, border=40, min_disparity=64.0)
+    dsel = disp.reshape(-1)[idx2]
+    assert np.all(dsel > 64.0)
+    assert idx2.size == np.count_nonzero(disp[40:200, 40:280] > 64.0)
+
+
+def test_pointcloud2_blob_82x82(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "pointcloud2_82x82.json")))
+    q = np.array([float.fromhex(h) for h in meta["q_hex"]])
+    disp = np.full((82, 82), 4.0, dtype=np.float32)
+    disp[40:42, 40:42] = np.array(meta["roi_disparities"], dtype=np.float32).reshape(2, 2)
+    pts = oracle.reproject(disp, q, border=40)
+    assert pts.nbytes == meta["row_step"] == meta["point_step"] * meta["width"]
+    want = np.frombuffer(bytes.fromhex(meta["data_hex"]), dtype=np.float32).reshape(-1, 4)
+    assert_points_close(pts, want, max_ulp=1)
+    assert pts.tobytes()[12:16] == bytes.fromhex("0000803f")
+
+
+def test_mono16_to_mono8_exact_on_k257():
+    # values k*257 map back to k exactly
+    img = synth_disparity(1, 0, 640, 480, "mono16")
+    out = oracle.mono16_to_mono8(img)
+    assert np.array_equal(out, (img // 257).astype(np.uint8))
+    # general values: round-half-even of v*255/65535 evaluated in float
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 65536, size=(50, 70)).astype(np.uint16)
+    ref = np.rint(img.astype(np.float32) * np.float32(255.0 / 65535.0)).clip(0, 255).astype(np.uint8)
+    assert np.array_equal(oracle.mono16_to_mono8(img), ref)
+
+
+def test_median_u8_against_numpy():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(40, 57)).astype(np.uint8)
+    for k in (3, 11):
+        r = k // 2
+        pad = np.pad(img, r, mode="edge")
+        win = np.lib.stride_tricks.sliding_window_view(pad, (k, k)).reshape(40, 57, k * k)
+        ref = np.sort(win, axis=-1)[..., (k * k) // 2]
+        assert np.array_equal(oracle.median_u8(img, k), ref)
