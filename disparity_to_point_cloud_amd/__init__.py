@@ -1,0 +1,26 @@
+"""disparity_to_point_cloud_amd -- MI355X-native disparity -> point-cloud path.
+
+The product is the C-ABI shared library `libd2pc.so` (include/d2pc.h) built
+from the hand-written gfx950 kernels under csrc/.  This package is only the
+Python plumbing used by the tests, bench.py and the multi-GPU harness:
+a ctypes binding of that ABI plus torch.distributed helpers.  It contains no
+compute path of its own and no CPU fallback: if the library is missing or no
+GPU is usable, calls raise.
+"""
+from .capi import (  # noqa: F401
+    D2pcError,
+    Context,
+    DTYPE_F32,
+    DTYPE_U8,
+    DTYPE_U16,
+    MODE_PARITY,
+    MODE_COMPACT,
+    CALIB_BLOB_BYTES,
+    abi_version,
+    device_count,
+    library_path,
+    load_library,
+    make_q,
+    roi_points,
+    status_string,
+)

@@ -1,0 +1,270 @@
+"""ctypes binding of include/d2pc.h (the C-ABI drop-in boundary).
+
+One-to-one with the header: every function the header declares is bound here
+and nothing else.  The binding never computes points itself.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libd2pc.so"
+
+DTYPE_F32, DTYPE_U8, DTYPE_U16 = 0, 1, 2
+MODE_PARITY, MODE_COMPACT = 0, 1
+CALIB_BLOB_BYTES = 136
+
+# every symbol include/d2pc.h declares (tests check the library exports all)
+ABI_SYMBOLS = [
+    "d2pc_abi_version", "d2pc_status_string", "d2pc_device_count", "d2pc_make_q", "d2pc_config_init",
+    "d2pc_create", "d2pc_destroy", "d2pc_last_error", "d2pc_set_q", "d2pc_get_q", "d2pc_set_border",
+    "d2pc_set_mode", "d2pc_get_config", "d2pc_export_calibration", "d2pc_import_calibration",
+    "d2pc_roi_points", "d2pc_cloud_meta_fill", "d2pc_process", "d2pc_process_device", "d2pc_reserve",
+    "d2pc_check_async_error", "d2pc_set_tuning",
+]
+
+
+class Config(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("device_id", ctypes.c_int32),
+        ("border", ctypes.c_int32),
+        ("mode", ctypes.c_int32),
+        ("min_disparity", ctypes.c_float),
+        ("compact_algo", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
+    ]
+
+
+class Field(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 8), ("offset", ctypes.c_uint32), ("datatype", ctypes.c_uint8),
+                ("count", ctypes.c_uint32)]
+
+
+class CloudMeta(ctypes.Structure):
+    _fields_ = [
+        ("height", ctypes.c_uint32), ("width", ctypes.c_uint32), ("point_step", ctypes.c_uint32),
+        ("row_step", ctypes.c_uint32), ("is_bigendian", ctypes.c_uint8), ("is_dense", ctypes.c_uint8),
+        ("n_fields", ctypes.c_uint32), ("fields", Field * 3),
+    ]
+
+
+class D2pcError(RuntimeError):
+    def __init__(self, status, message=""):
+        self.status = status
+        super().__init__(f"d2pc status {status} ({status_string(status)}): {message}")
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def load_library():
+    """Load libd2pc.so.  Raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch ships its own libamdhip64.so.7; import it first so both share ONE
+    # HIP runtime (same SONAME => the loader reuses the already-mapped copy).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing only; the ABI works without it
+        pass
+    L = ctypes.CDLL(path)
+    vp, cp = ctypes.c_void_p, ctypes.c_char_p
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.d2pc_abi_version.restype = ctypes.c_int
+    L.d2pc_status_string.argtypes = [ctypes.c_int]
+    L.d2pc_status_string.restype = cp
+    L.d2pc_device_count.restype = ctypes.c_int
+    L.d2pc_make_q.argtypes = [ctypes.c_double] * 5 + [ctypes.c_int, ctypes.c_int, dp]
+    L.d2pc_config_init.argtypes = [ctypes.POINTER(Config)]
+    L.d2pc_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
+    L.d2pc_destroy.argtypes = [vp]
+    L.d2pc_last_error.argtypes = [vp]
+    L.d2pc_last_error.restype = cp
+    L.d2pc_set_q.argtypes = [vp, dp]
+    L.d2pc_get_q.argtypes = [vp, dp]
+    L.d2pc_set_border.argtypes = [vp, ctypes.c_int]
+    L.d2pc_set_mode.argtypes = [vp, ctypes.c_int]
+    L.d2pc_get_config.argtypes = [vp, ctypes.POINTER(Config)]
+    L.d2pc_export_calibration.argtypes = [vp, vp]
+    L.d2pc_import_calibration.argtypes = [vp, vp, ctypes.c_size_t]
+    L.d2pc_roi_points.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.d2pc_roi_points.restype = ctypes.c_size_t
+    L.d2pc_cloud_meta_fill.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(CloudMeta)]
+    L.d2pc_process.argtypes = [vp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+                               vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.d2pc_process_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, vp, ctypes.c_size_t, vp,
+                                      vp]
+    L.d2pc_reserve.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.d2pc_check_async_error.argtypes = [vp]
+    L.d2pc_set_tuning.argtypes = [vp, cp, ctypes.c_int]
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int or fn.restype is None:
+            fn.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def abi_version() -> int:
+    return load_library().d2pc_abi_version()
+
+
+def status_string(status: int) -> str:
+    try:
+        return load_library().d2pc_status_string(int(status)).decode()
+    except ImportError:
+        return "?"
+
+
+def device_count() -> int:
+    return load_library().d2pc_device_count()
+
+
+def roi_points(width: int, height: int, border: int) -> int:
+    return int(load_library().d2pc_roi_points(width, height, border))
+
+
+def make_q(fx=714.24, fy=713.5, cx=376.0, cy=240.0, baseline=0.09, nx=752, ny=480) -> np.ndarray:
+    """hpp:66-71,84-104 defaults -> row-major 4x4 Q (host-only helper)."""
+    q = np.zeros(16, dtype=np.float64)
+    st = load_library().d2pc_make_q(fx, fy, cx, cy, baseline, nx, ny,
+                                    q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    if st:
+        raise D2pcError(st, "d2pc_make_q")
+    return q
+
+
+_NP2DT = {np.dtype(np.float32): DTYPE_F32, np.dtype(np.uint8): DTYPE_U8, np.dtype(np.uint16): DTYPE_U16}
+
+
+class Context:
+    """RAII wrapper of d2pc_ctx."""
+
+    def __init__(self, device_id=0, border=40, mode=MODE_PARITY, min_disparity=-np.inf, compact_algo=0, q=None):
+        self._L = load_library()
+        cfg = Config()
+        self._check(self._L.d2pc_config_init(ctypes.byref(cfg)), None)
+        cfg.device_id, cfg.border, cfg.mode = device_id, border, mode
+        cfg.min_disparity, cfg.compact_algo = min_disparity, compact_algo
+        h = ctypes.c_void_p()
+        st = self._L.d2pc_create(ctypes.byref(cfg), ctypes.byref(h))
+        if st:
+            raise D2pcError(st, "d2pc_create")
+        self._h = h
+        if q is not None:
+            self.set_q(q)
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, st, h="self"):
+        if st:
+            msg = ""
+            if h == "self" and getattr(self, "_h", None):
+                msg = self._L.d2pc_last_error(self._h).decode()
+            raise D2pcError(st, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.d2pc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- calibration ------------------------------------------------------
+    def set_q(self, q):
+        q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(16))
+        self._check(self._L.d2pc_set_q(self._h, q.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+
+    def get_q(self) -> np.ndarray:
+        q = np.zeros(16, dtype=np.float64)
+        self._check(self._L.d2pc_get_q(self._h, q.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return q
+
+    def set_border(self, border: int):
+        self._check(self._L.d2pc_set_border(self._h, border))
+
+    def set_mode(self, mode: int):
+        self._check(self._L.d2pc_set_mode(self._h, mode))
+
+    def config(self) -> Config:
+        cfg = Config()
+        self._check(self._L.d2pc_get_config(self._h, ctypes.byref(cfg)))
+        return cfg
+
+    def export_calibration(self) -> bytes:
+        buf = ctypes.create_string_buffer(CALIB_BLOB_BYTES)
+        self._check(self._L.d2pc_export_calibration(self._h, buf))
+        return buf.raw
+
+    def import_calibration(self, blob: bytes):
+        buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+        self._check(self._L.d2pc_import_calibration(self._h, buf, len(blob)))
+
+    def cloud_meta(self, n_points: int) -> CloudMeta:
+        m = CloudMeta()
+        self._check(self._L.d2pc_cloud_meta_fill(self._h, n_points, ctypes.byref(m)))
+        return m
+
+    def set_tuning(self, key: str, value: int):
+        self._check(self._L.d2pc_set_tuning(self._h, key.encode(), value))
+
+    def reserve(self, width, height, n_frames=1):
+        self._check(self._L.d2pc_reserve(self._h, width, height, n_frames))
+
+    def check_async_error(self):
+        self._check(self._L.d2pc_check_async_error(self._h))
+
+    # -- hot path: host buffers (d2pc_process) ------------------------------
+    def process(self, disp: np.ndarray, scale=1.0, want_index=False, capacity=None):
+        """(H,W) numpy disparity -> ((n,4) float32 points[, (n,) uint32 index])."""
+        if disp.ndim != 2 or disp.strides[1] != disp.itemsize:
+            raise ValueError("disp must be a 2-D array with contiguous rows")
+        dt = _NP2DT.get(disp.dtype)
+        if dt is None:
+            raise D2pcError(2, f"numpy dtype {disp.dtype}")
+        h, w = disp.shape
+        cfg = self.config()
+        cap = roi_points(w, h, cfg.border) if capacity is None else capacity
+        out = np.empty((max(cap, 1), 4), dtype=np.float32)
+        idx = np.empty(max(cap, 1), dtype=np.uint32) if want_index else None
+        n = ctypes.c_size_t(0)
+        st = self._L.d2pc_process(self._h, disp.ctypes.data, dt, scale, w, h, disp.strides[0], out.ctypes.data,
+                                  idx.ctypes.data if want_index else None, cap, ctypes.byref(n))
+        self._check(st)
+        if want_index:
+            return out[: n.value], idx[: n.value]
+        return out[: n.value]
+
+    # -- hot path: device-resident batch (d2pc_process_device) --------------
+    def process_device(self, d_disp_ptr, dtype, scale, width, height, row_stride, in_frame_stride, n_frames,
+                       d_out_ptr, d_index_ptr, out_frame_stride_points, d_counts_ptr, stream_ptr=None):
+        st = self._L.d2pc_process_device(self._h, d_disp_ptr, dtype, scale, width, height, row_stride,
+                                         in_frame_stride, n_frames, d_out_ptr, d_index_ptr,
+                                         out_frame_stride_points, d_counts_ptr, stream_ptr)
+        self._check(st)

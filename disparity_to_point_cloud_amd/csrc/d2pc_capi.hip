@@ -1,0 +1,470 @@
+// d2pc_capi.hip -- implementation of include/d2pc.h (the C-ABI drop-in
+// boundary for Disparity2PCloud::DisparityCb's cpp:63-85).  Owns the device
+// context: stream, staging buffers, compaction state.  No CPU compute path
+// exists here: every d2pc_process* call runs the HIP kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "../../include/d2pc.h"
+#include "d2pc_device.hpp"
+#include "d2pc_launch.hpp"
+
+using namespace d2pc;
+
+struct d2pc_ctx {
+  d2pc_config cfg{};
+  int device = 0;
+  int cu_count = 256;
+  hipStream_t stream = nullptr;
+  bool have_q = false;
+  double q[16] = {0};
+  // tuning (d2pc_set_tuning)
+  int pxt_parity = 4, pxt_compact = 8;
+  int blocks_per_cu = 8;
+  // device scratch
+  void *d_state = nullptr;   size_t state_cap = 0;
+  void *d_in = nullptr;      size_t in_cap = 0;
+  void *d_out = nullptr;     size_t out_cap = 0;
+  void *d_idx = nullptr;     size_t idx_cap = 0;
+  uint32_t *d_counts = nullptr;
+  uint32_t *h_counts = nullptr;  // pinned
+  char err[256] = {0};
+};
+
+namespace {
+
+int fail(d2pc_ctx *ctx, int status, const char *fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+    va_end(ap);
+  }
+  return status;
+}
+
+#define D2PC_HIP(ctx, call)                                                                   \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? D2PC_ERR_OUT_OF_MEMORY : D2PC_ERR_DEVICE,  \
+                  "%s failed: %s", #call, hipGetErrorString(e_));                             \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+size_t elem_size(int dtype) { return dtype == D2PC_DTYPE_F32 ? 4 : dtype == D2PC_DTYPE_U16 ? 2 : 1; }
+
+int grow(d2pc_ctx *ctx, void **p, size_t *cap, size_t need) {
+  if (need <= *cap) return D2PC_OK;
+  if (*p) {
+    D2PC_HIP(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+  }
+  size_t want = (need + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+  D2PC_HIP(ctx, hipMalloc(p, want));
+  *cap = want;
+  return D2PC_OK;
+}
+
+// Validates the frame description and fills the launch geometry.
+int make_geom(d2pc_ctx *ctx, int dtype, float scale, int width, int height, size_t row_stride,
+              size_t in_frame_stride, int n_frames, size_t out_frame_stride, int pxt, Geom *g) {
+  if (dtype != D2PC_DTYPE_F32 && dtype != D2PC_DTYPE_U8 && dtype != D2PC_DTYPE_U16)
+    return fail(ctx, D2PC_ERR_BAD_DTYPE, "dtype %d is not F32/U8/U16", dtype);
+  if (width <= 0 || height <= 0) return fail(ctx, D2PC_ERR_BAD_SIZE, "bad image size %dx%d", width, height);
+  if (uint64_t(width) * uint64_t(height) > (uint64_t(1) << 31))
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "image %dx%d exceeds 2^31 pixels", width, height);
+  const size_t es = elem_size(dtype);
+  if (row_stride < size_t(width) * es || row_stride % es != 0)
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "row stride %zu invalid for width %d (elem %zu B)", row_stride, width, es);
+  if (n_frames <= 0 || n_frames > 65535) return fail(ctx, D2PC_ERR_BAD_SIZE, "bad frame count %d", n_frames);
+  if (n_frames > 1 && (in_frame_stride < size_t(height) * row_stride || in_frame_stride % es != 0))
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "input frame stride %zu too small", in_frame_stride);
+  const int b = ctx->cfg.border;
+  memset(g, 0, sizeof *g);
+  g->width = uint32_t(width);
+  g->height = uint32_t(height);
+  g->border = uint32_t(b);
+  g->roi_w = width > 2 * b ? uint32_t(width - 2 * b) : 0u;
+  g->roi_h = height > 2 * b ? uint32_t(height - 2 * b) : 0u;
+  g->roi_n = g->roi_w * g->roi_h;
+  if (n_frames > 1 && out_frame_stride < g->roi_n)
+    return fail(ctx, D2PC_ERR_CAPACITY, "output frame stride %zu < %u ROI points", out_frame_stride, g->roi_n);
+  g->tile_px = 256u * uint32_t(pxt);
+  g->tiles_per_frame = (g->roi_n + g->tile_px - 1) / g->tile_px;
+  g->n_frames = uint32_t(n_frames);
+  const uint64_t total = uint64_t(g->tiles_per_frame) * g->n_frames;
+  if (total > 0x7fffffffull) return fail(ctx, D2PC_ERR_BAD_SIZE, "batch too large (%llu tiles)", (unsigned long long)total);
+  g->total_tiles = uint32_t(total);
+  g->groups_per_frame = (g->tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
+  g->div_roi_w = make_fastdiv(g->roi_w ? g->roi_w : 1u);
+  g->div_tpf = make_fastdiv(g->tiles_per_frame ? g->tiles_per_frame : 1u);
+  g->row_stride = row_stride;
+  g->in_frame_stride = in_frame_stride;
+  g->out_frame_stride = out_frame_stride;
+  g->scale = scale;
+  g->min_disparity = ctx->cfg.min_disparity;
+  return D2PC_OK;
+}
+
+int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d_out, uint32_t *d_idx,
+            uint32_t *d_counts, hipStream_t stream, bool allow_alloc) {
+  LaunchArgs a;
+  a.disp = d_disp;
+  a.out_points = d_out;
+  a.out_index = d_idx;
+  a.counts = d_counts;
+  a.dtype = dtype;
+  a.stream = stream;
+  a.geom = g;
+  memcpy(a.q.q, ctx->q, sizeof a.q.q);
+  const uint32_t resident = uint32_t(ctx->cu_count) * uint32_t(ctx->blocks_per_cu);
+  a.grid = g.total_tiles < resident ? g.total_tiles : resident;
+  if (a.grid == 0) a.grid = 1;
+  if (ctx->cfg.mode == D2PC_MODE_PARITY) {
+    a.pxt = ctx->pxt_parity;
+    D2PC_HIP(ctx, launch_parity(a));
+    return D2PC_OK;
+  }
+  if (!d_counts) return fail(ctx, D2PC_ERR_INVALID_ARG, "COMPACT mode needs a d_counts buffer");
+  a.pxt = ctx->pxt_compact;
+  a.compact_algo = ctx->cfg.compact_algo == 1 ? 1 : 2;
+  a.state_bytes = compact_state_bytes(g);
+  if (a.state_bytes > ctx->state_cap) {
+    if (!allow_alloc) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "compaction state not reserved (call d2pc_reserve)");
+    int st = grow(ctx, &ctx->d_state, &ctx->state_cap, a.state_bytes);
+    if (st != D2PC_OK) return st;
+  }
+  a.state = ctx->d_state;
+  D2PC_HIP(ctx, launch_compact(a));
+  return D2PC_OK;
+}
+
+bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) return false;
+  return st != hipStreamCaptureStatusNone;
+}
+
+}  // namespace
+
+extern "C" {
+
+int d2pc_abi_version(void) { return D2PC_ABI_VERSION; }
+
+const char *d2pc_status_string(int s) {
+  switch (s) {
+    case D2PC_OK: return "ok";
+    case D2PC_ERR_INVALID_ARG: return "invalid argument";
+    case D2PC_ERR_BAD_DTYPE: return "unsupported disparity dtype";
+    case D2PC_ERR_BAD_SIZE: return "bad image size or stride";
+    case D2PC_ERR_CAPACITY: return "output capacity too small";
+    case D2PC_ERR_NO_DEVICE: return "no usable HIP device";
+    case D2PC_ERR_DEVICE: return "HIP runtime error";
+    case D2PC_ERR_NOT_CALIBRATED: return "Q matrix not set";
+    case D2PC_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case D2PC_ERR_INTERNAL: return "internal error (compaction hand-off timed out)";
+  }
+  return "unknown status";
+}
+
+int d2pc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// hpp:84-104: cv::stereoRectify closed form for the reference rig (see
+// SURVEY.md section 8 row a9): f' = fy; c' = (n-1)/2 - f'((n-1)/2 - c)/f;
+// Q = [1 0 0 -cx'; 0 1 0 -cy'; 0 0 0 f'; 0 0 -1/Tx (cx1'-cx2')/Tx], Tx = -b.
+int d2pc_make_q(double fx, double fy, double cx, double cy, double baseline, int nx, int ny, double q[16]) {
+  if (!q || !(fx > 0) || !(fy > 0) || !(baseline != 0) || nx <= 0 || ny <= 0) return D2PC_ERR_INVALID_ARG;
+  const double f = fy;
+  const double hx = double(nx - 1) / 2.0, hy = double(ny - 1) / 2.0;
+  const double cxn = hx - f * (hx - cx) / fx;
+  const double cyn = hy - f * (hy - cy) / fy;
+  const double tx = -baseline;
+  for (int i = 0; i < 16; ++i) q[i] = 0.0;
+  q[0] = 1.0;  q[3] = -cxn;
+  q[5] = 1.0;  q[7] = -cyn;
+  q[11] = f;
+  q[14] = -1.0 / tx;
+  q[15] = (cxn - cxn) / tx;  // 0/Tx: keeps the sign OpenCV produces (-0.0 for Tx < 0)
+  return D2PC_OK;
+}
+
+int d2pc_config_init(d2pc_config *cfg) {
+  if (!cfg) return D2PC_ERR_INVALID_ARG;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = sizeof *cfg;
+  cfg->device_id = 0;
+  cfg->border = 40;  // cpp:70,72
+  cfg->mode = D2PC_MODE_PARITY;
+  cfg->min_disparity = -std::numeric_limits<float>::infinity();
+  cfg->compact_algo = 0;
+  return D2PC_OK;
+}
+
+int d2pc_create(const d2pc_config *cfg, d2pc_ctx **out) {
+  if (!cfg || !out) return D2PC_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(d2pc_config)) return D2PC_ERR_INVALID_ARG;
+  if (cfg->border < 0 || cfg->border > 16384) return D2PC_ERR_INVALID_ARG;
+  if (cfg->mode != D2PC_MODE_PARITY && cfg->mode != D2PC_MODE_COMPACT) return D2PC_ERR_INVALID_ARG;
+  if (cfg->compact_algo < 0 || cfg->compact_algo > 2) return D2PC_ERR_INVALID_ARG;
+  if (std::isnan(cfg->min_disparity)) return D2PC_ERR_INVALID_ARG;
+  int n = d2pc_device_count();
+  if (n <= 0 || cfg->device_id < 0 || cfg->device_id >= n) return D2PC_ERR_NO_DEVICE;
+  d2pc_ctx *ctx = new (std::nothrow) d2pc_ctx();
+  if (!ctx) return D2PC_ERR_OUT_OF_MEMORY;
+  ctx->cfg = *cfg;
+  ctx->device = cfg->device_id;
+  DeviceGuard guard(ctx->device);
+  hipDeviceProp_t prop;
+  if (!guard.ok || hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) {
+    delete ctx;
+    return D2PC_ERR_NO_DEVICE;
+  }
+  ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), 65536 * sizeof(uint32_t)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts), 65536 * sizeof(uint32_t), hipHostMallocDefault) !=
+          hipSuccess) {
+    d2pc_destroy(ctx);
+    return D2PC_ERR_DEVICE;
+  }
+  *out = ctx;
+  return D2PC_OK;
+}
+
+int d2pc_destroy(d2pc_ctx *ctx) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_state) (void)hipFree(ctx->d_state);
+  if (ctx->d_in) (void)hipFree(ctx->d_in);
+  if (ctx->d_out) (void)hipFree(ctx->d_out);
+  if (ctx->d_idx) (void)hipFree(ctx->d_idx);
+  if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+  if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return D2PC_OK;
+}
+
+const char *d2pc_last_error(const d2pc_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int d2pc_set_q(d2pc_ctx *ctx, const double q[16]) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!q) return fail(ctx, D2PC_ERR_INVALID_ARG, "q is null");
+  memcpy(ctx->q, q, sizeof ctx->q);  // bit copy: keeps -0.0 in Q[3][3]
+  ctx->have_q = true;
+  return D2PC_OK;
+}
+
+int d2pc_get_q(const d2pc_ctx *ctx, double q[16]) {
+  if (!ctx || !q) return D2PC_ERR_INVALID_ARG;
+  if (!ctx->have_q) return D2PC_ERR_NOT_CALIBRATED;
+  memcpy(q, ctx->q, sizeof ctx->q);
+  return D2PC_OK;
+}
+
+int d2pc_set_border(d2pc_ctx *ctx, int border) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (border < 0 || border > 16384) return fail(ctx, D2PC_ERR_INVALID_ARG, "bad border %d", border);
+  ctx->cfg.border = border;
+  return D2PC_OK;
+}
+
+int d2pc_set_mode(d2pc_ctx *ctx, int mode) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (mode != D2PC_MODE_PARITY && mode != D2PC_MODE_COMPACT) return fail(ctx, D2PC_ERR_INVALID_ARG, "bad mode %d", mode);
+  ctx->cfg.mode = mode;
+  return D2PC_OK;
+}
+
+int d2pc_get_config(const d2pc_ctx *ctx, d2pc_config *cfg) {
+  if (!ctx || !cfg) return D2PC_ERR_INVALID_ARG;
+  *cfg = ctx->cfg;
+  return D2PC_OK;
+}
+
+int d2pc_export_calibration(const d2pc_ctx *ctx, void *blob) {
+  if (!ctx || !blob) return D2PC_ERR_INVALID_ARG;
+  if (!ctx->have_q) return D2PC_ERR_NOT_CALIBRATED;
+  unsigned char *b = static_cast<unsigned char *>(blob);
+  memcpy(b, ctx->q, 128);
+  int32_t tail[2] = {ctx->cfg.border, ctx->cfg.mode};
+  memcpy(b + 128, tail, 8);
+  return D2PC_OK;
+}
+
+int d2pc_import_calibration(d2pc_ctx *ctx, const void *blob, size_t bytes) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!blob || bytes != D2PC_CALIB_BLOB_BYTES) return fail(ctx, D2PC_ERR_INVALID_ARG, "calibration blob must be %d bytes", D2PC_CALIB_BLOB_BYTES);
+  const unsigned char *b = static_cast<const unsigned char *>(blob);
+  int32_t tail[2];
+  memcpy(tail, b + 128, 8);
+  if (tail[0] < 0 || tail[0] > 16384 || (tail[1] != D2PC_MODE_PARITY && tail[1] != D2PC_MODE_COMPACT))
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "calibration blob carries border %d mode %d", tail[0], tail[1]);
+  memcpy(ctx->q, b, 128);
+  ctx->have_q = true;
+  ctx->cfg.border = tail[0];
+  ctx->cfg.mode = tail[1];
+  return D2PC_OK;
+}
+
+size_t d2pc_roi_points(int width, int height, int border) {
+  if (border < 0) return 0;
+  const long long w = (long long)width - 2LL * border, h = (long long)height - 2LL * border;
+  return (w > 0 && h > 0) ? size_t(w) * size_t(h) : 0;
+}
+
+// cpp:79-85: width = N, height = 1, is_dense = false; toROSMsg's field table.
+int d2pc_cloud_meta_fill(const d2pc_ctx *ctx, size_t n, d2pc_cloud_meta *m) {
+  if (!ctx || !m) return D2PC_ERR_INVALID_ARG;
+  if (n > 0xffffffffull / 16) return D2PC_ERR_BAD_SIZE;
+  memset(m, 0, sizeof *m);
+  m->height = 1;
+  m->width = uint32_t(n);
+  m->point_step = 16;
+  m->row_step = uint32_t(16 * n);
+  m->is_bigendian = 0;
+  m->is_dense = ctx->cfg.mode == D2PC_MODE_COMPACT ? 1 : 0;
+  m->n_fields = 3;
+  const char *names[3] = {"x", "y", "z"};
+  for (int i = 0; i < 3; ++i) {
+    strncpy(m->fields[i].name, names[i], sizeof m->fields[i].name - 1);
+    m->fields[i].offset = uint32_t(4 * i);
+    m->fields[i].datatype = 7;  // sensor_msgs::PointField::FLOAT32
+    m->fields[i].count = 1;
+  }
+  return D2PC_OK;
+}
+
+int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
+  if (!ctx || !key) return D2PC_ERR_INVALID_ARG;
+  if (!strcmp(key, "pxt_parity") && tile_shape_supported(value)) ctx->pxt_parity = value;
+  else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
+  else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 64) ctx->blocks_per_cu = value;
+  else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
+  return D2PC_OK;
+}
+
+int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  Geom g;
+  int st = make_geom(ctx, D2PC_DTYPE_F32, 1.f, width, height, size_t(width) * 4, size_t(width) * 4 * height, n_frames,
+                     d2pc_roi_points(width, height, ctx->cfg.border), ctx->pxt_compact, &g);
+  if (st != D2PC_OK) return st;
+  // the smallest supported tile gives the largest state
+  Geom g4 = g;
+  g4.tile_px = 256u * 4u;
+  g4.tiles_per_frame = (g.roi_n + g4.tile_px - 1) / g4.tile_px;
+  g4.groups_per_frame = (g4.tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
+  return grow(ctx, &ctx->d_state, &ctx->state_cap, compact_state_bytes(g4));
+}
+
+int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scale, int width, int height,
+                        size_t row_stride, size_t in_frame_stride, int n_frames, void *d_out, uint32_t *d_idx,
+                        size_t out_frame_stride, uint32_t *d_counts, void *stream) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!d_disp || !d_out) return fail(ctx, D2PC_ERR_INVALID_ARG, "null device pointer");
+  if (!ctx->have_q) return fail(ctx, D2PC_ERR_NOT_CALIBRATED, "Q matrix not set");
+  if (reinterpret_cast<uintptr_t>(d_out) % 16 != 0) return fail(ctx, D2PC_ERR_INVALID_ARG, "d_out_points must be 16-byte aligned");
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
+  Geom g;
+  int st = make_geom(ctx, dtype, scale, width, height, row_stride, in_frame_stride, n_frames, out_frame_stride,
+                     compact ? ctx->pxt_compact : ctx->pxt_parity, &g);
+  if (st != D2PC_OK) return st;
+  if (reinterpret_cast<uintptr_t>(d_disp) % elem_size(dtype) != 0)
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "d_disp is not aligned to its sample type");
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  if (g.roi_n == 0) {
+    if (d_counts) D2PC_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * size_t(n_frames), s));
+    return D2PC_OK;
+  }
+  return enqueue(ctx, g, d_disp, dtype, d_out, d_idx, d_counts, s, !stream_is_capturing(s));
+}
+
+int d2pc_check_async_error(d2pc_ctx *ctx) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!ctx->d_state) return D2PC_OK;
+  DeviceGuard guard(ctx->device);
+  CompactHeader h;
+  D2PC_HIP(ctx, hipMemcpy(&h, ctx->d_state, sizeof h, hipMemcpyDeviceToHost));
+  if (h.timeout) return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
+  return D2PC_OK;
+}
+
+int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int width, int height,
+                 size_t row_stride, void *out_points, uint32_t *out_index, size_t capacity, size_t *n_points) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (n_points) *n_points = 0;
+  if (!disp || !n_points) return fail(ctx, D2PC_ERR_INVALID_ARG, "null argument");
+  if (!ctx->have_q) return fail(ctx, D2PC_ERR_NOT_CALIBRATED, "Q matrix not set");
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
+  if (dtype != D2PC_DTYPE_F32 && dtype != D2PC_DTYPE_U8 && dtype != D2PC_DTYPE_U16)
+    return fail(ctx, D2PC_ERR_BAD_DTYPE, "dtype %d is not F32/U8/U16", dtype);
+  const size_t es = elem_size(dtype);
+  // device copy of the frame is packed to a 256-byte pitch
+  const size_t pitch = (size_t(width > 0 ? width : 0) * es + 255) & ~size_t(255);
+  Geom g;
+  int st = make_geom(ctx, dtype, scale, width, height, row_stride, 0, 1, 0, compact ? ctx->pxt_compact : ctx->pxt_parity, &g);
+  if (st != D2PC_OK) return st;
+  if (g.roi_n == 0) return D2PC_OK;  // cpp:70,72: empty loops => empty cloud
+  if (!out_points) return fail(ctx, D2PC_ERR_INVALID_ARG, "out_points is null");
+  if (!compact && capacity < g.roi_n)
+    return fail(ctx, D2PC_ERR_CAPACITY, "capacity %zu < %u ROI points", capacity, g.roi_n);
+  g.row_stride = pitch;
+  if ((st = grow(ctx, &ctx->d_in, &ctx->in_cap, pitch * size_t(height))) != D2PC_OK) return st;
+  if ((st = grow(ctx, &ctx->d_out, &ctx->out_cap, size_t(g.roi_n) * 16)) != D2PC_OK) return st;
+  if (out_index && (st = grow(ctx, &ctx->d_idx, &ctx->idx_cap, size_t(g.roi_n) * 4)) != D2PC_OK) return st;
+  hipStream_t s = ctx->stream;
+  D2PC_HIP(ctx, hipMemcpy2DAsync(ctx->d_in, pitch, disp, row_stride, size_t(width) * es, size_t(height),
+                                 hipMemcpyHostToDevice, s));
+  st = enqueue(ctx, g, ctx->d_in, dtype, ctx->d_out, out_index ? static_cast<uint32_t *>(ctx->d_idx) : nullptr,
+               ctx->d_counts, s, true);
+  if (st != D2PC_OK) return st;
+  size_t n = g.roi_n;
+  if (compact) {
+    D2PC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    D2PC_HIP(ctx, hipStreamSynchronize(s));
+    if (ctx->cfg.compact_algo != 1 && (st = d2pc_check_async_error(ctx)) != D2PC_OK) return st;
+    n = ctx->h_counts[0];
+    if (n > capacity) return fail(ctx, D2PC_ERR_CAPACITY, "capacity %zu < %zu valid points", capacity, n);
+  }
+  if (n) {
+    D2PC_HIP(ctx, hipMemcpyAsync(out_points, ctx->d_out, n * 16, hipMemcpyDeviceToHost, s));
+    if (out_index) D2PC_HIP(ctx, hipMemcpyAsync(out_index, ctx->d_idx, n * 4, hipMemcpyDeviceToHost, s));
+  }
+  D2PC_HIP(ctx, hipStreamSynchronize(s));
+  *n_points = n;
+  return D2PC_OK;
+}
+
+}  // extern "C"

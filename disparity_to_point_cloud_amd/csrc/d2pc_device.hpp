@@ -1,0 +1,74 @@
+// d2pc_device.hpp -- shared host/device definitions for the gfx950 kernels.
+//
+// Replaces, on the device, the three scalar CPU loops of
+// Disparity2PCloud::DisparityCb (reference src/disparity_to_point_cloud.cpp):
+//   :63-64  cv::reprojectImageTo3D      (Q . (u,v,d,1), perspective divide)
+//   :70-76  ROI inset push_back loop    (row-major gather, 12 B -> 16 B)
+//   :84-85  pcl::toROSMsg               (memcpy into PointCloud2.data)
+// One pass: 4 B read, 16 B written per ROI pixel, straight into the final
+// PointCloud2 byte layout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace d2pc {
+
+// ---- exact unsigned division by a launch-time constant --------------------
+// Granlund-Montgomery round-up method: q = (t + ((n - t) >> s1)) >> s2 with
+// t = mulhi(m, n); exact for every 32-bit n and every 1 <= d < 2^32.
+struct FastDiv {
+  uint32_t m, s1, s2, d;
+};
+
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t l = 0;
+  while (l < 32 && (uint64_t(1) << l) < d) ++l;  // l = ceil(log2 d)
+  f.m = uint32_t(((uint64_t(1) << 32) * ((uint64_t(1) << l) - d)) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l == 0 ? 0 : l - 1;
+  return f;
+}
+
+__host__ __device__ inline uint32_t fdiv(uint32_t n, const FastDiv &f) {
+  const uint32_t t = uint32_t((uint64_t(f.m) * n) >> 32);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+// ---- launch geometry (kernarg; lives in SGPRs) ----------------------------
+struct Geom {
+  uint32_t width, height, border;
+  uint32_t roi_w, roi_h, roi_n;       // ROI size; roi_n = roi_w*roi_h points
+  uint32_t tile_px;                   // ROI pixels per tile (= BLOCK*PXT)
+  uint32_t tiles_per_frame, n_frames, total_tiles;
+  uint32_t groups_per_frame;          // compaction: ceil(tiles_per_frame/64)
+  FastDiv div_roi_w, div_tpf;
+  uint64_t row_stride;                // bytes between image rows
+  uint64_t in_frame_stride;           // bytes between frames
+  uint64_t out_frame_stride;          // points between frames' outputs
+  float scale;                        // U8/U16 decode: d = (float)raw*scale
+  float min_disparity;                // compact predicate: drop d <= this
+};
+
+// Q_ (reference hpp:72): row-major 4x4 doubles.  Kernarg => scalar registers,
+// i.e. one copy per wave with no LDS or vector-memory traffic at all.
+struct QMat {
+  double q[16];
+};
+
+enum : int { DT_F32 = 0, DT_U8 = 1, DT_U16 = 2 };
+
+// Compaction hand-off state (zeroed by a memset node before every launch).
+struct CompactHeader {
+  uint32_t ticket;        // single-pass: next tile to hand out
+  uint32_t timeout;       // set to 1 if a bounded spin expired
+  uint32_t pad[14];       // keep the header on its own 64-byte line
+};
+
+constexpr uint64_t kGranuleTag = uint64_t(1) << 63;
+constexpr int kGroupTiles = 64;         // tiles per counting group
+constexpr uint32_t kSpinLimit = 1u << 22;
+
+}  // namespace d2pc

@@ -1,0 +1,34 @@
+// d2pc_launch.hpp -- host-side launch interface between the C ABI
+// (d2pc_capi.hip) and the kernels (d2pc_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "d2pc_device.hpp"
+
+namespace d2pc {
+
+struct LaunchArgs {
+  const void *disp = nullptr;     // device: n_frames disparity images
+  void *out_points = nullptr;     // device: 16-byte points
+  uint32_t *out_index = nullptr;  // device, nullable
+  uint32_t *counts = nullptr;     // device, nullable (required in COMPACT)
+  void *state = nullptr;          // device: compaction state (COMPACT)
+  size_t state_bytes = 0;
+  int dtype = DT_F32;
+  int pxt = 4;                    // ROI pixels per thread (tile = 256*pxt)
+  int compact_algo = 2;           // 1 two-pass, 2 single-pass
+  uint32_t grid = 1;
+  hipStream_t stream = nullptr;
+  Geom geom{};
+  QMat q{};
+};
+
+bool tile_shape_supported(int pxt);
+size_t compact_state_bytes(const Geom &g);
+hipError_t launch_parity(const LaunchArgs &a);
+hipError_t launch_compact(const LaunchArgs &a);
+
+}  // namespace d2pc

@@ -1,0 +1,180 @@
+/*
+ * d2pc.h -- C ABI of the MI355X-native disparity -> point-cloud path.
+ *
+ * Drop-in boundary for ONE path of PX4/disparity_to_point_cloud: the body of
+ * d2pc::Disparity2PCloud::DisparityCb between
+ *     real_disparity            (src/disparity_to_point_cloud.cpp:60-61)
+ * and
+ *     sensor_msgs::PointCloud2 output.data / width / ...   (cpp:84-85)
+ * i.e. cv::reprojectImageTo3D (cpp:63-64) + the inset-40 ROI push_back loop
+ * (cpp:70-76) + cloud metadata (cpp:79-81) + pcl::toROSMsg (cpp:84-85).
+ * The reference has no FFI/plugin interface; a maintainer binds these entry
+ * points from DisparityCb as shown in INTEGRATION.md.
+ *
+ * Plain C: pointers and sizes only.  No HIP, torch, ROS, OpenCV or PCL types.
+ * Every function returns a d2pc_status (0 = OK) and never throws or aborts.
+ * There is NO CPU fallback inside this library: without a usable gfx950
+ * device d2pc_create() fails with D2PC_ERR_NO_DEVICE.
+ *
+ * Threading (mirrors the reference's single-threaded ros::spin(),
+ * src/disparity_to_point_cloud_node.cpp:50): a context is not thread-safe;
+ * distinct contexts (one per GPU / per camera stream) are independent.
+ */
+#ifndef D2PC_H
+#define D2PC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D2PC_ABI_VERSION 1
+
+typedef enum d2pc_status {
+  D2PC_OK = 0,
+  D2PC_ERR_INVALID_ARG = 1,   /* null pointer, bad struct_size, bad enum      */
+  D2PC_ERR_BAD_DTYPE = 2,     /* dtype not one of D2PC_DTYPE_*                */
+  D2PC_ERR_BAD_SIZE = 3,      /* width/height/stride out of range             */
+  D2PC_ERR_CAPACITY = 4,      /* output buffer too small for the points       */
+  D2PC_ERR_NO_DEVICE = 5,     /* no HIP device / device_id out of range       */
+  D2PC_ERR_DEVICE = 6,        /* a HIP call failed (see d2pc_last_error)      */
+  D2PC_ERR_NOT_CALIBRATED = 7,/* d2pc_set_q / d2pc_set_calibration not called */
+  D2PC_ERR_OUT_OF_MEMORY = 8,
+  D2PC_ERR_INTERNAL = 9       /* compaction hand-off timed out (bounded spin) */
+} d2pc_status;
+
+/* Sample type of the disparity image handed over.
+ * F32 is the reference's `real_disparity` (CV_32FC1, cpp:60-61).
+ * U8/U16 fuse the reference's convertTo(CV_32FC1, scale) (cpp:61) into the
+ * kernel: d = (float)raw * scale in fp32 (scale = 1/8 in the reference). */
+typedef enum d2pc_dtype { D2PC_DTYPE_F32 = 0, D2PC_DTYPE_U8 = 1, D2PC_DTYPE_U16 = 2 } d2pc_dtype;
+
+typedef enum d2pc_mode {
+  /* What the reference publishes (cpp:70-81): every ROI pixel, row-major,
+   * nothing filtered (inf/NaN included), N = (W-2b)(H-2b), is_dense=false. */
+  D2PC_MODE_PARITY = 0,
+  /* Extension named by BASELINE.json's north_star: order-preserving removal
+   * of points with a non-finite coordinate (or d <= min_disparity); the
+   * survivors keep row-major order, so the cloud is dense (is_dense=true). */
+  D2PC_MODE_COMPACT = 1
+} d2pc_mode;
+
+typedef struct d2pc_config {
+  uint32_t struct_size;   /* = sizeof(d2pc_config); set by d2pc_config_init   */
+  int32_t device_id;      /* HIP device ordinal (rank-local GPU)              */
+  int32_t border;         /* ROI inset on all four sides; cpp:70,72 => 40     */
+  int32_t mode;           /* d2pc_mode                                        */
+  float min_disparity;    /* COMPACT only: also drop d <= this; -inf = off    */
+  int32_t compact_algo;   /* 0 = library default; 1 = two-pass count/scatter;
+                             2 = single-pass counted hand-off                 */
+  int32_t reserved[4];
+} d2pc_config;
+
+typedef struct d2pc_ctx d2pc_ctx;
+
+/* sensor_msgs/PointCloud2 metadata that pcl::toROSMsg (cpp:84-85) fills for a
+ * pcl::PointCloud<pcl::PointXYZ> of n points with cpp:79-81's width/height. */
+typedef struct d2pc_field { char name[8]; uint32_t offset; uint8_t datatype; uint32_t count; } d2pc_field;
+typedef struct d2pc_cloud_meta {
+  uint32_t height;        /* 1  (cpp:80)                                      */
+  uint32_t width;         /* n  (cpp:79)                                      */
+  uint32_t point_step;    /* 16 = sizeof(pcl::PointXYZ)                       */
+  uint32_t row_step;      /* 16*n                                             */
+  uint8_t is_bigendian;   /* 0                                                */
+  uint8_t is_dense;       /* 0 in PARITY (cpp:81), 1 in COMPACT               */
+  uint32_t n_fields;      /* 3                                                */
+  d2pc_field fields[3];   /* x,y,z FLOAT32(7) @ 0,4,8 count 1                 */
+} d2pc_cloud_meta;
+
+/* Calibration blob broadcast once from rank 0 to every GPU's process
+ * (RCCL/xGMI broadcast in the multi-GPU harness): 16 x f64 Q + border + mode. */
+#define D2PC_CALIB_BLOB_BYTES 136
+
+/* ---- library-level ---------------------------------------------------- */
+int d2pc_abi_version(void);
+const char *d2pc_status_string(int status);
+int d2pc_device_count(void);            /* number of HIP devices, 0 if none  */
+
+/* ---- calibration surface (hpp:66-71,84-104) --------------------------- */
+/* Closed form of the reference's cv::stereoRectify call for its rig
+ * (identical pinhole cameras, zero distortion, R = I, t = (-baseline,0,0),
+ * image size (nx,ny) = (752,480) at hpp:101-103).  Host-only helper for
+ * ROS-free callers; the ROS adaptor passes OpenCV's own Q_ to d2pc_set_q. */
+int d2pc_make_q(double fx, double fy, double cx, double cy, double baseline,
+                int nx, int ny, double q_out[16]);
+
+/* ---- context ---------------------------------------------------------- */
+int d2pc_config_init(d2pc_config *cfg); /* reference defaults: border 40, PARITY */
+int d2pc_create(const d2pc_config *cfg, d2pc_ctx **out_ctx);
+int d2pc_destroy(d2pc_ctx *ctx);
+const char *d2pc_last_error(const d2pc_ctx *ctx);
+
+/* Q_ (hpp:72), row-major 4x4 doubles exactly as Q_.ptr<double>() yields. */
+int d2pc_set_q(d2pc_ctx *ctx, const double q[16]);
+int d2pc_get_q(const d2pc_ctx *ctx, double q_out[16]);
+int d2pc_set_border(d2pc_ctx *ctx, int border);
+int d2pc_set_mode(d2pc_ctx *ctx, int mode);
+int d2pc_get_config(const d2pc_ctx *ctx, d2pc_config *cfg_out);
+int d2pc_export_calibration(const d2pc_ctx *ctx, void *blob /*136 B*/);
+int d2pc_import_calibration(d2pc_ctx *ctx, const void *blob, size_t blob_bytes);
+
+/* Number of ROI pixels (= points in PARITY mode): max(w-2b,0)*max(h-2b,0). */
+size_t d2pc_roi_points(int width, int height, int border);
+int d2pc_cloud_meta_fill(const d2pc_ctx *ctx, size_t n_points, d2pc_cloud_meta *meta);
+
+/* ---- the hot path ----------------------------------------------------- */
+/*
+ * Replaces cpp:63-85 for one frame held in HOST memory (synchronous).
+ *   disp              H x W samples of `dtype`, rows `row_stride_bytes` apart
+ *   scale             U8/U16 only (cpp:61: 1/8); ignored for F32
+ *   out_points        capacity_points records of 16 bytes {x,y,z,1.0f}: the
+ *                     exact bytes of PointCloud2.data (pass output.data.data())
+ *   out_index         nullable; source pixel index v*W+u of every emitted
+ *                     point (uint32)
+ *   n_points          points written: (W-2b)(H-2b) in PARITY, #valid in COMPACT
+ * Nothing is retained after return.
+ */
+int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale,
+                 int width, int height, size_t row_stride_bytes,
+                 void *out_points, uint32_t *out_index,
+                 size_t capacity_points, size_t *n_points);
+
+/*
+ * Device-resident, batched, asynchronous form (frames already in HBM):
+ * n_frames frames, `in_frame_stride_bytes` apart, are converted by ONE
+ * kernel sequence enqueued on `stream` (a hipStream_t passed as void*;
+ * NULL = the context's own stream).  Frame f's points go to
+ * d_out_points + f*out_frame_stride_points*16 (and d_out_index +
+ * f*out_frame_stride_points); d_counts[f] (uint32, nullable in PARITY)
+ * receives the number of points of frame f.  All device pointers must belong
+ * to the context's device; d_out_points must be 16-byte aligned.
+ * Does not synchronise.  Call d2pc_reserve first if the call must be
+ * capturable into a hipGraph (no allocation happens then).
+ */
+int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype,
+                        float scale, int width, int height,
+                        size_t row_stride_bytes, size_t in_frame_stride_bytes,
+                        int n_frames, void *d_out_points,
+                        uint32_t *d_out_index,
+                        size_t out_frame_stride_points, uint32_t *d_counts,
+                        void *stream);
+
+/* Pre-size the context's scratch (tile state, staging) for frames up to
+ * width x height and batches up to n_frames. */
+int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames);
+
+/* COMPACT single-pass only: after the stream has been synchronised, returns
+ * D2PC_ERR_INTERNAL if any bounded hand-off spin expired in the last launch. */
+int d2pc_check_async_error(d2pc_ctx *ctx);
+
+/* Launch-shape tuning hook (no counterpart in the reference; results never
+ * depend on it).  Keys: "pxt_parity", "pxt_compact" (ROI pixels per thread:
+ * 4, 8 or 16), "blocks_per_cu" (resident 256-thread blocks per CU, 1..64). */
+int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2PC_H */

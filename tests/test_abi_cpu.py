@@ -1,0 +1,137 @@
+"""CPU tests of the C-ABI surface: the library loads, exports every symbol
+include/d2pc.h declares, and its host-only entry points behave.  No compute
+calls (there is no GPU here and the library has no CPU path)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import disparity_to_point_cloud_amd as d2pc
+from disparity_to_point_cloud_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "d2pc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(d2pc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = d2pc.load_library()
+    declared = _header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"libd2pc.so does not export {name}"
+    assert sorted(capi.ABI_SYMBOLS) == declared, "python binding and header disagree"
+
+
+def test_abi_version_and_status_strings():
+    assert d2pc.abi_version() == 1
+    assert d2pc.status_string(0) == "ok"
+    for s in range(1, 10):
+        assert d2pc.status_string(s) not in ("", "ok", "unknown status")
+    assert d2pc.status_string(99) == "unknown status"
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(capi.Config) == 40
+    cfg = capi.Config()
+    assert d2pc.load_library().d2pc_config_init(ctypes.byref(cfg)) == 0
+    # reference defaults: border 40 (cpp:70,72), unfiltered output (cpp:81)
+    assert (cfg.struct_size, cfg.border, cfg.mode, cfg.device_id) == (40, 40, d2pc.MODE_PARITY, 0)
+    assert cfg.min_disparity == -np.inf
+    assert ctypes.sizeof(capi.Field) == 20 and ctypes.sizeof(capi.CloudMeta) == 84
+
+
+def test_make_q_matches_oracle_bitwise():
+    import oracle
+
+    for kw in (dict(), dict(fx=500.0, fy=510.0, cx=300.5, cy=200.25, baseline=0.043, nx=640, ny=480)):
+        a = d2pc.make_q(**kw)
+        b = oracle.make_q(**kw)
+        assert a.tobytes() == b.tobytes()
+    q = d2pc.make_q()
+    assert np.signbit(q[15]) and q[15] == 0.0  # Q[3][3] = -0.0
+    lib = d2pc.load_library()
+    assert lib.d2pc_make_q(0.0, 1.0, 0.0, 0.0, 0.1, 10, 10, q.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 1
+    assert lib.d2pc_make_q(1.0, 1.0, 0.0, 0.0, 0.1, 10, 10, None) == 1
+
+
+def test_roi_points():
+    assert d2pc.roi_points(752, 480, 40) == 672 * 400  # native geometry, BASELINE.md
+    assert d2pc.roi_points(640, 480, 40) == 224000
+    assert d2pc.roi_points(1920, 1080, 40) == 1840000
+    assert d2pc.roi_points(3840, 2160, 40) == 7820800
+    assert d2pc.roi_points(80, 480, 40) == 0 and d2pc.roi_points(81, 81, 40) == 1
+    assert d2pc.roi_points(10, 10, -1) == 0
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_config():
+    lib = d2pc.load_library()
+    h = ctypes.c_void_p()
+    cfg = capi.Config()
+    lib.d2pc_config_init(ctypes.byref(cfg))
+    assert lib.d2pc_create(None, ctypes.byref(h)) == 1
+    assert lib.d2pc_create(ctypes.byref(cfg), None) == 1
+    bad = capi.Config.from_buffer_copy(cfg)
+    bad.struct_size = 12
+    assert lib.d2pc_create(ctypes.byref(bad), ctypes.byref(h)) == 1
+    bad = capi.Config.from_buffer_copy(cfg)
+    bad.mode = 7
+    assert lib.d2pc_create(ctypes.byref(bad), ctypes.byref(h)) == 1
+    bad = capi.Config.from_buffer_copy(cfg)
+    bad.border = -1
+    assert lib.d2pc_create(ctypes.byref(bad), ctypes.byref(h)) == 1
+    if d2pc.device_count() == 0:
+        # no CPU fallback: a valid request without a GPU is an error, not a slow path
+        assert lib.d2pc_create(ctypes.byref(cfg), ctypes.byref(h)) == 5
+        with pytest.raises(d2pc.D2pcError) as e:
+            d2pc.Context()
+        assert e.value.status == 5
+    bad = capi.Config.from_buffer_copy(cfg)
+    bad.device_id = 1 << 20
+    assert lib.d2pc_create(ctypes.byref(bad), ctypes.byref(h)) == 5
+
+
+def test_null_context_calls_return_invalid_arg():
+    lib = d2pc.load_library()
+    q = np.zeros(16)
+    qp = q.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    n = ctypes.c_size_t()
+    assert lib.d2pc_set_q(None, qp) == 1
+    assert lib.d2pc_get_q(None, qp) == 1
+    assert lib.d2pc_destroy(None) == 1
+    assert lib.d2pc_set_border(None, 3) == 1 and lib.d2pc_set_mode(None, 0) == 1
+    assert lib.d2pc_process(None, None, 0, 1.0, 1, 1, 4, None, None, 0, ctypes.byref(n)) == 1
+    assert lib.d2pc_process_device(None, None, 0, 1.0, 1, 1, 4, 4, 1, None, None, 0, None, None) == 1
+    assert lib.d2pc_reserve(None, 1, 1, 1) == 1 and lib.d2pc_check_async_error(None) == 1
+    assert lib.d2pc_last_error(None) == b"null context"
+
+
+def test_fastdiv_reference_model():
+    """The kernels' exact division (csrc/d2pc_device.hpp make_fastdiv/fdiv),
+    modelled in python: q == n // d for all probed 32-bit n."""
+    rng = np.random.default_rng(1)
+
+    def mk(d):
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        m = ((1 << 32) * ((1 << l) - d)) // d + 1
+        return m & 0xFFFFFFFF, min(l, 1), max(l - 1, 0)
+
+    ds = [1, 2, 3, 5, 7, 16, 560, 672, 1840, 3760, 3840, 65535, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1]
+    ds += list(rng.integers(1, 2 ** 32, size=200))
+    for d in ds:
+        d = int(d)
+        m, s1, s2 = mk(d)
+        ns = np.concatenate([rng.integers(0, 2 ** 32, size=2000, dtype=np.uint64),
+                             np.array([0, 1, d - 1, d, d + 1, 2 ** 32 - 1, (2 ** 32 - 1) // d * d], dtype=np.uint64)])
+        ns = ns[ns < 2 ** 32]
+        t = (ns * np.uint64(m)) >> np.uint64(32)
+        q = ((t + ((ns - t) >> np.uint64(s1))) & np.uint64(0xFFFFFFFF)) >> np.uint64(s2)
+        assert np.array_equal(q, ns // np.uint64(d)), d

@@ -1,0 +1,119 @@
+"""GPU tests of the device-resident batched entry point (d2pc_process_device)
+at BASELINE.json's full sizes, driven through torch device memory/streams."""
+import numpy as np
+import pytest
+
+import disparity_to_point_cloud_amd as d2pc
+import oracle
+from helpers import assert_points_close, synth_disparity
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _batch(ctx, frames, want_index):
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+
+    n, (h, w) = len(frames), frames[0].shape
+    tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8}[frames[0].dtype]
+    b = DeviceBatch(ctx, n, h, w, dtype=tdt, want_index=want_index)
+    b.disp.copy_(torch.from_numpy(np.stack(frames)))
+    b.points.fill_(float("nan"))
+    return b
+
+
+@pytest.mark.parametrize("border", [40, 0])
+def test_c4_4k_parity_batch(border):
+    """configs[3]: 3840x2160 fp32 stream, PARITY, border 40 and 0."""
+    q = d2pc.make_q()
+    frames = [synth_disparity(4, f, 3840, 2160, "uniform") for f in range(3)]
+    with d2pc.Context(q=q, border=border) as ctx:
+        b = _batch(ctx, frames, want_index=False)
+        b.launch()
+        res = b.results()
+    for f, (pts, _) in enumerate(res):
+        want = oracle.reproject(frames[f], q, border=border, threads=8)
+        assert len(pts) == (3840 - 2 * border) * (2160 - 2 * border)
+        assert_points_close(pts, want, max_ulp=1, rel=1e-5, what=f"4K frame {f}")
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_c4_4k_compact_batch(algo):
+    q = d2pc.make_q()
+    kinds = ["uniform", "holes", "blocky", "holes"]
+    frames = [synth_disparity(4, 10 + f, 3840, 2160, k) for f, k in enumerate(kinds)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+        b = _batch(ctx, frames, want_index=True)
+        for _ in range(3):  # relaunch: state must re-initialise every call
+            b.launch()
+        res = b.results()
+        ctx.check_async_error()
+    for f, (pts, idx) in enumerate(res):
+        wp, wi = oracle.reproject_compact(frames[f], q, border=40)
+        assert len(pts) == len(wp), f"frame {f} count"
+        assert np.array_equal(idx, wi), f"frame {f} indices"
+        assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"4K compact frame {f}")
+
+
+def test_batch_u8_native_geometry():
+    q = d2pc.make_q()
+    rng = np.random.default_rng(21)
+    frames = [rng.integers(0, 256, size=(480, 752)).astype(np.uint8) for _ in range(5)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        b = _batch(ctx, frames, want_index=True)
+        b.launch(scale=0.125)
+        res = b.results()
+    for f, (pts, idx) in enumerate(res):
+        wp, wi = oracle.reproject_compact(frames[f], q, border=40, scale=0.125)
+        assert np.array_equal(idx, wi)
+        assert_points_close(pts, wp, max_ulp=1)
+
+
+def test_compact_is_idempotent_and_sorted_at_full_size():
+    """Size-independent properties at 4K: indices strictly increasing; the
+    points gathered by those indices from a PARITY run equal the COMPACT
+    points bit-for-bit; counts equal the number of finite PARITY points."""
+    q = d2pc.make_q()
+    frames = [synth_disparity(4, 20, 3840, 2160, "holes")]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as c, d2pc.Context(q=q) as p:
+        bc = _batch(c, frames, want_index=True)
+        bp = _batch(p, frames, want_index=False)
+        bc.launch()
+        bp.launch()
+        (cp, ci), = bc.results()
+        (pp, _), = bp.results()
+    assert np.all(np.diff(ci.astype(np.int64)) > 0)
+    keep = np.isfinite(pp[:, :3]).all(axis=1)
+    assert keep.sum() == len(cp)
+    assert np.array_equal(pp[keep].view(np.uint32), cp.view(np.uint32))
+    v, u = np.divmod(ci.astype(np.int64), 3840)
+    roi = (v - 40) * 3760 + (u - 40)
+    assert np.array_equal(roi, np.nonzero(keep)[0])
+
+
+def test_launch_on_side_stream_and_graph_capture():
+    q = d2pc.make_q()
+    frames = [synth_disparity(2, f, 640, 480, "holes") for f in range(4)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        b = _batch(ctx, frames, want_index=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            b.launch()
+        side.synchronize()
+        first = b.results()
+        # capture the same call into a hipGraph and replay it
+        b.points.fill_(0)
+        b.counts.fill_(0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            b.launch()
+        g.replay()
+        g.replay()
+        second = b.results()
+    for (p1, i1), (p2, i2), fr in zip(first, second, frames):
+        wp, wi = oracle.reproject_compact(fr, q, border=40)
+        assert np.array_equal(i1, wi) and np.array_equal(i2, wi)
+        assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32))
+        assert_points_close(p1, wp, max_ulp=1)

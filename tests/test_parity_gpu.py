@@ -1,0 +1,306 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/d2pc.h),
+against the CPU oracle and the exact-rational golden vectors.
+
+Bar (BASELINE.json north_star): pixel indices and point counts bit-exact;
+XYZ within 1e-5 relative of the CPU loop -- asserted here far tighter, at
+<= 1 float32 ulp, with identical NaN/inf classes and the pad word 0x3F800000.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import disparity_to_point_cloud_amd as d2pc
+import oracle
+from helpers import assert_points_close, synth_disparity, ulp_distance
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5  # north_star tolerance
+MAX_ULP = 1     # what we actually hold
+
+
+@pytest.fixture(scope="module")
+def q_default():
+    return d2pc.make_q()
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "reproject_exact.npz"))
+
+
+def ctx_for(q, **kw):
+    return d2pc.Context(q=q, **kw)
+
+
+# ---------------------------------------------------------------- parity mode
+@pytest.mark.parametrize("name", ["A_default_q_k8", "B_dense_q", "C_extremes"])
+def test_golden_exact_rational(golden, name):
+    q = golden[name + "__q"]
+    border = int(golden[name + "__border"])
+    exp = golden[name + "__expected_bits"].view(np.float32)
+    disp = golden[name + "__disp"]
+    with ctx_for(q, border=border) as ctx:
+        got = ctx.process(disp)
+    assert_points_close(got, exp, max_ulp=MAX_ULP, rel=REL_TOL, what=name)
+    assert (ulp_distance(got[:, :3], exp[:, :3]) == 0).mean() > 0.99
+
+
+def test_golden_u8_centre_rows(golden):
+    name = "D_centre_rows_u8"
+    q = golden[name + "__q"]
+    exp = golden[name + "__expected_bits"].view(np.float32)
+    r0, r1 = golden[name + "__rows"]
+    rows = golden[name + "__raw_u8_rows"]
+    raw = np.ones((r1, rows.shape[1]), dtype=np.uint8)
+    raw[r0:r1] = rows
+    w = raw.shape[1]
+    with ctx_for(q, border=0) as ctx:
+        got = ctx.process(raw, scale=0.125)  # fused cpp:61 decode
+        got_f = ctx.process(raw.astype(np.float32) * np.float32(0.125))
+    assert_points_close(got[r0 * w : r1 * w], exp, max_ulp=MAX_ULP, rel=REL_TOL, what=name)
+    assert np.array_equal(got.view(np.uint32), got_f.view(np.uint32))
+    y240 = got[240 * w : 241 * w, 1]
+    assert np.all(y240 == 0)
+
+
+def test_pointcloud2_blob_and_meta(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "pointcloud2_82x82.json")))
+    q = np.array([float.fromhex(h) for h in meta["q_hex"]])
+    disp = np.full((82, 82), 4.0, dtype=np.float32)
+    disp[40:42, 40:42] = np.array(meta["roi_disparities"], dtype=np.float32).reshape(2, 2)
+    with ctx_for(q) as ctx:
+        pts = ctx.process(disp)
+        m = ctx.cloud_meta(len(pts))
+    want = np.frombuffer(bytes.fromhex(meta["data_hex"]), dtype=np.float32).reshape(-1, 4)
+    assert_points_close(pts, want, max_ulp=MAX_ULP)
+    assert (m.height, m.width, m.point_step, m.row_step) == (1, 4, 16, 64)
+    assert (m.is_bigendian, m.is_dense, m.n_fields) == (0, 0, 3)
+    for f, ref in zip(m.fields, meta["fields"]):
+        assert (f.name.decode(), f.offset, f.datatype, f.count) == (ref["name"], ref["offset"], ref["datatype"],
+                                                                  ref["count"])
+
+
+def test_c2_640x480_fp32_vs_cpu(q_default):
+    """BASELINE.json configs[1]: 640x480 fp32, d = k/8, validate XYZ vs CPU."""
+    disp = synth_disparity(2, 0, 640, 480, "k8")
+    want = oracle.reproject(disp, q_default, border=40)
+    with ctx_for(q_default) as ctx:
+        got, idx = ctx.process(disp, want_index=True)
+    assert got.shape == (224000, 4)
+    assert_points_close(got, want, max_ulp=MAX_ULP, rel=REL_TOL, what="C2")
+    v, u = np.mgrid[40:440, 40:600]
+    assert np.array_equal(idx, (v * 640 + u).reshape(-1).astype(np.uint32))
+    # also within tolerance of the OpenCV-4 form of the same loop
+    want4 = oracle.reproject(disp, q_default, border=40, form=oracle.FORM_CV4)
+    assert_points_close(got, want4, max_ulp=2, rel=REL_TOL, what="C2/cv4")
+
+
+def test_native_752x480_u8_as_the_reference_feeds_it(q_default):
+    """The reference's own geometry and input: 8-bit disparity, x1/8."""
+    rng = np.random.default_rng(11)
+    raw = rng.integers(0, 256, size=(480, 752)).astype(np.uint8)  # zeros included
+    want = oracle.reproject(raw, q_default, border=40, scale=0.125)
+    with ctx_for(q_default) as ctx:
+        got = ctx.process(raw, scale=0.125)
+    assert got.shape == (268800, 4)
+    assert_points_close(got, want, max_ulp=MAX_ULP, rel=REL_TOL, what="752x480 u8")
+    assert np.isinf(got[:, 2]).sum() == np.count_nonzero(raw[40:440, 40:712] == 0)
+
+
+def test_c1_mono16_plumbing(q_default):
+    """configs[0]: uint16 k*257 published as mono16; cv_bridge maps it to k
+    (cpp:50), then the reference's /8 decode.  Here: U16 input, scale such
+    that d = (v/257)/8."""
+    img = synth_disparity(1, 0, 640, 480, "mono16")
+    mono8 = oracle.mono16_to_mono8(img)
+    want = oracle.reproject(mono8, q_default, border=40, scale=0.125)
+    with ctx_for(q_default) as ctx:
+        got = ctx.process(mono8, scale=0.125)
+        got16 = ctx.process(img, scale=float(np.float32(0.125) / np.float32(257)))
+    assert got.shape == (224000, 4)
+    assert_points_close(got, want, max_ulp=MAX_ULP, rel=REL_TOL, what="C1")
+    m8 = oracle.reproject(img, q_default, border=40, scale=float(np.float32(0.125) / np.float32(257)))
+    assert_points_close(got16, m8, max_ulp=MAX_ULP, rel=REL_TOL, what="C1/u16")
+
+
+def test_zero_disparity_inf_nan_pattern(q_default):
+    disp = np.zeros((330, 752), dtype=np.float32)
+    want = oracle.reproject(disp, q_default, border=40)
+    with ctx_for(q_default) as ctx:
+        got = ctx.process(disp)
+    assert_points_close(got, want, what="d=0")
+    g = got.reshape(250, 672, 4)
+    v, u = np.mgrid[40:290, 40:712]
+    assert np.all(np.isposinf(g[..., 2]))
+    assert np.array_equal(np.isnan(g[..., 1]), v == 240)
+    assert np.array_equal(np.isneginf(g[..., 0]), u < 375.9995)
+
+
+def test_nan_and_inf_disparities(q_default):
+    disp = synth_disparity(2, 5, 200, 120, "uniform")
+    disp[50, 60] = np.nan
+    disp[51, 61] = np.inf
+    disp[52, 62] = -np.inf
+    disp[53, 63] = -3.0
+    want = oracle.reproject(disp, q_default, border=40)
+    with ctx_for(q_default) as ctx:
+        got = ctx.process(disp)
+    assert_points_close(got, want, max_ulp=MAX_ULP, what="nan/inf d")
+
+
+@pytest.mark.parametrize("w,h,border", [(96, 96, 40), (81, 81, 40), (97, 83, 40), (131, 97, 5), (1, 1, 0),
+                                        (3, 1000, 0), (1000, 3, 0), (1025, 9, 0), (257, 263, 7), (4099, 5, 1)])
+def test_ragged_sizes(w, h, border):
+    rng = np.random.default_rng(w * 10007 + h)
+    q = rng.uniform(-1, 1, 16)
+    q[12:16] = [2e-4, 1e-4, 0.03, 0.7]
+    disp = rng.uniform(0.5, 128, size=(h, w)).astype(np.float32)
+    want = oracle.reproject(disp, q, border=border)
+    with ctx_for(q, border=border) as ctx:
+        got, idx = ctx.process(disp, want_index=True)
+    assert_points_close(got, want, max_ulp=MAX_ULP, rel=REL_TOL, what=f"{w}x{h}")
+    v, u = np.mgrid[border : h - border, border : w - border]
+    assert np.array_equal(idx, (v * w + u).reshape(-1).astype(np.uint32))
+
+
+@pytest.mark.parametrize("w,h", [(80, 80), (80, 200), (200, 80), (79, 300), (40, 40)])
+def test_empty_roi(w, h, q_default):
+    disp = np.ones((h, w), dtype=np.float32)
+    with ctx_for(q_default) as ctx:
+        got = ctx.process(disp)
+        assert got.shape == (0, 4)
+        ctx.set_mode(d2pc.MODE_COMPACT)
+        got = ctx.process(disp)
+        assert got.shape == (0, 4)
+
+
+def test_row_stride(q_default):
+    big = synth_disparity(2, 1, 300, 150, "k8")
+    view = big[:, 17:250]
+    want = oracle.reproject(np.ascontiguousarray(view), q_default, border=10)
+    with ctx_for(q_default, border=10) as ctx:
+        got = ctx.process(view)
+    assert_points_close(got, want, max_ulp=MAX_ULP)
+
+
+@pytest.mark.parametrize("pxt", [4, 8, 16])
+def test_tile_shapes_agree_bitwise(q_default, pxt):
+    disp = synth_disparity(3, 2, 500, 300, "holes")
+    with ctx_for(q_default) as ctx:
+        ref = ctx.process(disp)
+        ctx.set_tuning("pxt_parity", pxt)
+        ctx.set_tuning("blocks_per_cu", 1)
+        got = ctx.process(disp)
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+
+
+# --------------------------------------------------------------- compact mode
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("kind", ["holes", "blocky", "uniform"])
+def test_compact_vs_oracle_small(q_default, kind, algo):
+    disp = synth_disparity(3, 0, 640, 360, kind)
+    wp, wi = oracle.reproject_compact(disp, q_default, border=40)
+    with ctx_for(q_default, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+        gp, gi = ctx.process(disp, want_index=True)
+        m = ctx.cloud_meta(len(gp))
+    assert len(gp) == len(wp), "point count must be bit-exact"
+    assert np.array_equal(gi, wi), "pixel indices must be bit-exact and in row-major order"
+    assert_points_close(gp, wp, max_ulp=MAX_ULP, rel=REL_TOL, what=f"compact {kind}")
+    assert m.is_dense == 1 and m.width == len(gp)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_c3_1080p_30pct_invalid(q_default, algo):
+    """BASELINE.json configs[2]: 1920x1080 fp32, ~30 % invalid, compaction on."""
+    for kind in ("holes", "blocky"):
+        disp = synth_disparity(3, 1, 1920, 1080, kind)
+        wp, wi = oracle.reproject_compact(disp, q_default, border=40)
+        with ctx_for(q_default, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+            gp, gi = ctx.process(disp, want_index=True)
+        assert len(gp) == len(wp)
+        assert np.array_equal(gi, wi)
+        assert_points_close(gp, wp, max_ulp=MAX_ULP, rel=REL_TOL, what=f"C3 {kind}")
+        assert 0.6 < len(gp) / 1840000 < 0.8
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("pxt", [4, 8, 16])
+def test_compact_edge_patterns(q_default, algo, pxt):
+    rng = np.random.default_rng(99)
+    base = rng.uniform(0.5, 128, size=(200, 333)).astype(np.float32)
+    patterns = {
+        "all_invalid": np.zeros_like(base),
+        "all_valid": base,
+        "checker": np.where((np.indices(base.shape).sum(0) & 1) == 0, base, 0).astype(np.float32),
+        "one_valid": np.where(np.arange(base.size).reshape(base.shape) == 12345, base, 0).astype(np.float32),
+        "last_only": np.where(np.arange(base.size).reshape(base.shape) == base.size - 1, base, 0).astype(np.float32),
+    }
+    with ctx_for(q_default, border=0, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+        ctx.set_tuning("pxt_compact", pxt)
+        for name, disp in patterns.items():
+            wp, wi = oracle.reproject_compact(disp, q_default, border=0)
+            gp, gi = ctx.process(disp, want_index=True)
+            assert len(gp) == len(wp), name
+            assert np.array_equal(gi, wi), name
+            assert_points_close(gp, wp, max_ulp=MAX_ULP, what=name)
+
+
+def test_compact_min_disparity(q_default):
+    disp = synth_disparity(3, 3, 400, 300, "holes")
+    wp, wi = oracle.reproject_compact(disp, q_default, border=40, min_disparity=64.0)
+    with ctx_for(q_default, mode=d2pc.MODE_COMPACT, min_disparity=64.0) as ctx:
+        gp, gi = ctx.process(disp, want_index=True)
+    assert np.array_equal(gi, wi)
+    assert_points_close(gp, wp, max_ulp=MAX_ULP)
+
+
+def test_compact_capacity_error(q_default):
+    disp = synth_disparity(3, 4, 300, 200, "uniform")
+    with ctx_for(q_default, mode=d2pc.MODE_COMPACT) as ctx:
+        with pytest.raises(d2pc.D2pcError) as e:
+            ctx.process(disp, capacity=100)
+        assert e.value.status == 4
+
+
+# ------------------------------------------------------------- ABI misuse (T4)
+def test_abi_misuse_returns_codes(q_default):
+    lib = d2pc.load_library()
+    disp = np.ones((100, 100), dtype=np.float32)
+    out = np.empty((400, 4), dtype=np.float32)
+    n = ctypes.c_size_t()
+    with d2pc.Context(border=40) as ctx:
+        h = ctx.handle
+        args = lambda **k: [  # noqa: E731
+            h, k.get("disp", disp.ctypes.data), k.get("dtype", 0), 1.0, k.get("w", 100), k.get("h", 100),
+            k.get("stride", 400), k.get("out", out.ctypes.data), None, k.get("cap", 400), ctypes.byref(n)]
+        assert lib.d2pc_process(*args()) == 7  # Q not set
+        ctx.set_q(q_default)
+        assert lib.d2pc_process(*args()) == 0 and n.value == 400
+        assert lib.d2pc_process(*args(disp=None)) == 1
+        assert lib.d2pc_process(*args(out=None)) == 1
+        assert lib.d2pc_process(*args(dtype=5)) == 2
+        assert lib.d2pc_process(*args(w=0)) == 3
+        assert lib.d2pc_process(*args(h=-4)) == 3
+        assert lib.d2pc_process(*args(stride=396)) == 3
+        assert lib.d2pc_process(*args(stride=402)) == 3
+        assert lib.d2pc_process(*args(cap=399)) == 4
+        assert b"capacity" in lib.d2pc_last_error(h)
+        assert n.value == 0
+        # context still usable after errors
+        assert lib.d2pc_process(*args()) == 0 and n.value == 400
+
+
+def test_calibration_blob_roundtrip(q_default):
+    with ctx_for(q_default, border=13, mode=d2pc.MODE_COMPACT) as a, d2pc.Context() as b:
+        blob = a.export_calibration()
+        assert len(blob) == d2pc.CALIB_BLOB_BYTES
+        b.import_calibration(blob)
+        assert b.get_q().tobytes() == q_default.tobytes()
+        cfg = b.config()
+        assert (cfg.border, cfg.mode) == (13, d2pc.MODE_COMPACT)
+        with pytest.raises(d2pc.D2pcError):
+            b.import_calibration(blob[:-1])
