@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the disparity -> point-cloud hot path.
+
+Metric (BASELINE.json): Mpixels/s reprojected, device-resident, on the
+3840x2160 fp32 disparity stream (configs[3]; configs[4] = one such stream per
+GPU).  A "step" is ONE pass of the hot path (one d2pc_process_device call)
+over a ring of 16 distinct synthetic 4K frames already resident in HBM
+(531 MB in, 2.0 GB out: larger than the 256 MiB Infinity Cache).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with `roofline` (algorithmic bytes / measured
+kernel time vs 8 TB/s HBM peak) and `cpu_baseline` (the oracle's single-thread
+restatement of the reference loop timed on this host, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import disparity_to_point_cloud_amd as d2pc  # noqa: E402
+from disparity_to_point_cloud_amd import multi_gpu  # noqa: E402
+from disparity_to_point_cloud_amd.synth import synth_disparity  # noqa: E402
+from disparity_to_point_cloud_amd.torch_api import DeviceBatch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+W4K, H4K = 3840, 2160
+
+
+def fill_batch(batch, rank, kind):
+    """Ring of distinct seeded frames (config 4), different per rank."""
+    for f in range(batch.n_frames):
+        fr = synth_disparity(4, rank * batch.n_frames + f, batch.width, batch.height, kind)
+        batch.disp[f].copy_(torch.from_numpy(fr))
+    torch.cuda.synchronize()
+
+
+def algorithmic_bytes(batch, n_points, with_index):
+    """bytes = 4*R_in + 16*P (+4*P with indices), per launch."""
+    r_in = batch.n_frames * batch.roi_n
+    return 4 * r_in + (20 if with_index else 16) * n_points
+
+
+def timed_steps(batch, steps, warmup, dist_sync):
+    for _ in range(warmup):
+        batch.launch()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    dist_sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()  # HIP events on the stream the kernels are launched on
+        batch.launch()
+        e1.record()
+    torch.cuda.synchronize()
+    dist_sync()
+    t1 = time.perf_counter()
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    return t1 - t0, float(np.mean(kernel_ms))
+
+
+def cpu_baseline(q, border, budget_s=12.0):
+    """The CPU restatement of cpp:63-85 (oracle, kind "port") on the same 4K
+    workload, single thread like the reference's ros::spin(); bounded sample."""
+    import oracle
+
+    fr = synth_disparity(4, 0, W4K, H4K, "uniform")
+    buf = oracle.reproject(fr, q, border=border)  # warm; output buffer reused below
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        oracle.reproject(fr, q, border=border, threads=1, out=buf)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 64:
+            break
+    one = W4K * H4K * n / el / 1e6
+    nt = oracle.max_threads()
+    oracle.reproject(fr, q, border=border, threads=nt, out=buf)  # start the OpenMP team
+    t0 = time.perf_counter()
+    m = 0
+    while True:
+        oracle.reproject(fr, q, border=border, threads=nt, out=buf)
+        m += 1
+        el2 = time.perf_counter() - t0
+        if el2 > budget_s / 3 or m >= 64:
+            break
+    allc = W4K * H4K * m / el2 / 1e6
+    return {
+        "value": round(one, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+        "sample": f"{n} frames of 3840x2160 fp32 (config 4, border {border}), oracle/d2pc_oracle.c FORM_CV24, "
+                  f"{el:.1f} s",
+        "all_cores": {"value": round(allc, 2), "cores": nt, "sample": f"{m} frames, OpenMP over rows, {el2:.1f} s"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=16, help="frames per step (ring size)")
+    ap.add_argument("--border", type=int, default=40, help="ROI inset (reference: 40)")
+    ap.add_argument("--mode", choices=["parity", "compact"], default="parity")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    rank, local_rank, world = multi_gpu.init_distributed()
+    assert world == max(a.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {a.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    mode = d2pc.MODE_PARITY if a.mode == "parity" else d2pc.MODE_COMPACT
+
+    # calibration: rank 0 owns it, everyone else receives the 136-byte blob
+    ctx = d2pc.Context(device_id=local_rank, border=a.border, mode=mode)
+    if rank == 0:
+        ctx.set_q(d2pc.make_q())
+    multi_gpu.broadcast_calibration(ctx, src=0)
+    q = ctx.get_q()
+
+    batch = DeviceBatch(ctx, a.frames, H4K, W4K, want_index=False, device=dev)
+    fill_batch(batch, rank, "uniform")
+    batch.launch()
+    torch.cuda.synchronize()
+    n_points = int(batch.counts.sum().item())
+
+    wall, kernel_ms = timed_steps(batch, a.steps, a.warmup, multi_gpu.barrier)
+    wall = multi_gpu.allreduce_max(wall)
+    kernel_ms_max = multi_gpu.allreduce_max(kernel_ms)
+    if mode == d2pc.MODE_COMPACT:
+        ctx.check_async_error()
+
+    pixels_per_step = a.frames * W4K * H4K
+    value = world * pixels_per_step * a.steps / wall / 1e6
+    alg = algorithmic_bytes(batch, n_points, False)
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "Mpixels/s reprojected (device-resident)",
+        "value": round(value, 1),
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(wall / a.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"config 4: {a.frames} x 3840x2160 fp32 disparity frames per step, d~U(0.5,128), "
+                        f"border {a.border}, mode {a.mode}, one stream per GPU, Q broadcast from rank 0",
+            "frames_per_step": a.frames, "width": W4K, "height": H4K, "border": a.border, "mode": a.mode,
+            "points_per_step": n_points,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "k_reproject_pack" if mode == d2pc.MODE_PARITY else "k_compact_onepass",
+            "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": round(kernel_ms, 4),
+            "kernel_ms_avg_max_over_ranks": round(kernel_ms_max, 4),
+            "read_component_GBs": round(4 * a.frames * batch.roi_n / (kernel_ms * 1e-3) / 1e9, 1),
+        },
+    }
+    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(prof):
+        try:
+            t = json.load(open(prof)).get(f"{a.mode}_border{a.border}_frames{a.frames}")
+            if t:
+                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = t.get("source")
+        except Exception:
+            pass
+
+    if rank == 0 and not a.no_variants:
+        variants = {}
+        for name, vmode, vborder, kind, idx in (
+            ("parity_border0", d2pc.MODE_PARITY, 0, "uniform", False),
+            ("compact_border40_all_valid", d2pc.MODE_COMPACT, 40, "uniform", False),
+            ("compact_border40_30pct_holes_index", d2pc.MODE_COMPACT, 40, "holes", True),
+        ):
+            c2 = d2pc.Context(device_id=local_rank, border=vborder, mode=vmode, q=q)
+            b2 = DeviceBatch(c2, a.frames, H4K, W4K, want_index=idx, device=dev)
+            if kind == "uniform":
+                b2.disp.copy_(batch.disp)
+            else:
+                fill_batch(b2, rank, kind)
+            b2.launch()
+            torch.cuda.synchronize()
+            npts = int(b2.counts.sum().item())
+            _, kms = timed_steps(b2, max(a.steps // 4, 5), 3, lambda: None)
+            ab = algorithmic_bytes(b2, npts, idx)
+            variants[name] = {"Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1),
+                              "achieved_GBs": round(ab / (kms * 1e-3) / 1e9, 1),
+                              "frac": round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "kernel_ms_avg": round(kms, 4), "points_per_step": npts}
+            if vmode == d2pc.MODE_COMPACT:
+                c2.check_async_error()
+            del b2
+            c2.close()
+        out["variants_1gpu"] = variants
+    if rank == 0 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(q, a.border)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    multi_gpu.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

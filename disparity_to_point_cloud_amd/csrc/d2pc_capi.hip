@@ -401,7 +401,7 @@ int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scal
   if (st != D2PC_OK) return st;
   if (reinterpret_cast<uintptr_t>(d_disp) % elem_size(dtype) != 0)
     return fail(ctx, D2PC_ERR_INVALID_ARG, "d_disp is not aligned to its sample type");
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   if (g.roi_n == 0) {
     if (d_counts) D2PC_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * size_t(n_frames), s));
     return D2PC_OK;

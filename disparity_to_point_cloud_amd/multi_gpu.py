@@ -1,0 +1,94 @@
+"""One-process-per-GPU sharding of the path.
+
+Frames are independent units: every rank owns one camera stream / frame queue
+and one GPU; nothing crosses GPUs on the per-frame path.  The ONLY exchange is
+the calibration: rank 0 broadcasts the 136-byte blob (16 x f64 Q + border +
+mode) once at start-up / on recalibration -- RCCL over xGMI when the backend
+is "nccl", gloo in the CPU tests.  Reporting uses one all-reduce of counters.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a
+    single process).  Returns (rank, local_rank, world_size)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def _comm_device():
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def broadcast_blob(blob, src=0) -> bytes:
+    """Broadcast the calibration blob from `src`; every rank returns the bytes."""
+    n = capi.CALIB_BLOB_BYTES
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        assert blob is not None and len(blob) == n
+        return bytes(blob)
+    dev = _comm_device()
+    if dist.get_rank() == src:
+        assert blob is not None and len(blob) == n
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    else:
+        t = torch.zeros(n, dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy().tobytes()
+
+
+def broadcast_calibration(ctx, src=0):
+    """Rank `src` exports its context's calibration; every other rank imports
+    it, so all GPUs reproject with bit-identical Q / border / mode."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    blob = ctx.export_calibration() if rank == src else None
+    blob = broadcast_blob(blob, src)
+    if rank != src:
+        ctx.import_calibration(blob)
+    return blob
+
+
+def shard_frames(n_frames_total: int, rank: int, world: int):
+    """Frame-level data parallelism for ONE shared stream: frame i goes to
+    rank i % world (round-robin keeps per-rank order == arrival order)."""
+    return list(range(rank, n_frames_total, world))
+
+
+def allreduce_max(x: float) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(x)
+    t = torch.tensor([x], dtype=torch.float64, device=_comm_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_sum_counters(counters) -> np.ndarray:
+    """Sum of per-rank {frames, pixels, points, ns} style counters."""
+    t = torch.tensor(list(counters), dtype=torch.int64, device=_comm_device())
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -145,7 +145,7 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale,
  * Device-resident, batched, asynchronous form (frames already in HBM):
  * n_frames frames, `in_frame_stride_bytes` apart, are converted by ONE
  * kernel sequence enqueued on `stream` (a hipStream_t passed as void*;
- * NULL = the context's own stream).  Frame f's points go to
+ * NULL = HIP's default stream, as in the HIP API).  Frame f's points go to
  * d_out_points + f*out_frame_stride_points*16 (and d_out_index +
  * f*out_frame_stride_points); d_counts[f] (uint32, nullable in PARITY)
  * receives the number of points of frame f.  All device pointers must belong

@@ -80,12 +80,15 @@ def make_q(fx=714.24, fy=713.5, cx=376.0, cy=240.0, baseline=0.09, nx=752, ny=48
     return q
 
 
-def reproject(disp: np.ndarray, q, border=40, scale=1.0, form=FORM_CV24, threads=1) -> np.ndarray:
-    """(H,W) disparity -> (R,4) float32 points, reference (unfiltered) semantics."""
+def reproject(disp: np.ndarray, q, border=40, scale=1.0, form=FORM_CV24, threads=1, out=None) -> np.ndarray:
+    """(H,W) disparity -> (R,4) float32 points, reference (unfiltered) semantics.
+    `out` lets a timing loop reuse one output buffer."""
     assert disp.ndim == 2 and disp.strides[1] == disp.itemsize
     h, w = disp.shape
     rw, rh = max(w - 2 * border, 0), max(h - 2 * border, 0)
-    out = np.empty((rw * rh, 4), dtype=np.float32)
+    if out is None:
+        out = np.empty((rw * rh, 4), dtype=np.float32)
+    assert out.shape == (rw * rh, 4) and out.dtype == np.float32 and out.flags.c_contiguous
     qk, qp = _q_ptr(q)
     n = lib().d2pc_oracle_reproject(disp.ctypes.data, dtype_code(disp), scale, w, h, disp.strides[0], qp,
                                     border, form, threads, out.ctypes.data)
