@@ -24,9 +24,12 @@ struct d2pc_ctx {
   hipStream_t stream = nullptr;
   bool have_q = false;
   double q[16] = {0};
-  // tuning (d2pc_set_tuning)
-  int pxt_parity = 4, pxt_compact = 8;
-  int blocks_per_cu = 8;
+  int q_kind = QK_GENERAL;
+  QStereo qs{};
+  // tuning (d2pc_set_tuning); defaults from tools/tune.py on MI355X
+  int pxt_parity = 8, pxt_compact = 8;
+  int blocks_per_cu = 16;
+  int force_general_q = 0;
   // device scratch
   void *d_state = nullptr;   size_t state_cap = 0;
   void *d_in = nullptr;      size_t in_cap = 0;
@@ -99,26 +102,36 @@ int make_geom(d2pc_ctx *ctx, int dtype, float scale, int width, int height, size
   if (n_frames <= 0 || n_frames > 65535) return fail(ctx, D2PC_ERR_BAD_SIZE, "bad frame count %d", n_frames);
   if (n_frames > 1 && (in_frame_stride < size_t(height) * row_stride || in_frame_stride % es != 0))
     return fail(ctx, D2PC_ERR_BAD_SIZE, "input frame stride %zu too small", in_frame_stride);
+  // 32-bit byte offsets inside a frame, with room for the tail slots of the
+  // last tile (up to 16*256 pixels past the ROI end)
+  if ((uint64_t(height) + 4097) * row_stride > 0xffffffffull)
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "frame of %d rows x %zu bytes exceeds 32-bit addressing", height, row_stride);
   const int b = ctx->cfg.border;
   memset(g, 0, sizeof *g);
   g->width = uint32_t(width);
-  g->height = uint32_t(height);
   g->border = uint32_t(b);
   g->roi_w = width > 2 * b ? uint32_t(width - 2 * b) : 0u;
-  g->roi_h = height > 2 * b ? uint32_t(height - 2 * b) : 0u;
-  g->roi_n = g->roi_w * g->roi_h;
+  const uint32_t roi_h = height > 2 * b ? uint32_t(height - 2 * b) : 0u;
+  if (uint64_t(g->roi_w) * roi_h > (uint64_t(1) << 28))
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "ROI of %u x %u exceeds 2^28 points", g->roi_w, roi_h);
+  g->roi_n = g->roi_w * roi_h;
   if (n_frames > 1 && out_frame_stride < g->roi_n)
     return fail(ctx, D2PC_ERR_CAPACITY, "output frame stride %zu < %u ROI points", out_frame_stride, g->roi_n);
-  g->tile_px = 256u * uint32_t(pxt);
-  g->tiles_per_frame = (g->roi_n + g->tile_px - 1) / g->tile_px;
+  const uint32_t tile_px = uint32_t(kBlock) * uint32_t(pxt);
+  g->tiles_per_frame = (g->roi_n + tile_px - 1) / tile_px;
   g->n_frames = uint32_t(n_frames);
   const uint64_t total = uint64_t(g->tiles_per_frame) * g->n_frames;
   if (total > 0x7fffffffull) return fail(ctx, D2PC_ERR_BAD_SIZE, "batch too large (%llu tiles)", (unsigned long long)total);
   g->total_tiles = uint32_t(total);
   g->groups_per_frame = (g->tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
-  g->div_roi_w = make_fastdiv(g->roi_w ? g->roi_w : 1u);
+  g->frame_state_stride = frame_state_stride(g->tiles_per_frame);
+  const uint32_t rw = g->roi_w ? g->roi_w : 1u;
+  g->step_v = uint32_t(kBlock) / rw;
+  g->step_u = uint32_t(kBlock) % rw;
+  g->div_roi_w = make_fastdiv(rw);
   g->div_tpf = make_fastdiv(g->tiles_per_frame ? g->tiles_per_frame : 1u);
-  g->row_stride = row_stride;
+  g->row_stride = uint32_t(row_stride);
+  g->last_off = g->roi_n ? uint32_t((uint64_t(b) + roi_h - 1) * row_stride + (uint64_t(b) + g->roi_w - 1) * es) : 0u;
   g->in_frame_stride = in_frame_stride;
   g->out_frame_stride = out_frame_stride;
   g->scale = scale;
@@ -137,6 +150,8 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   a.stream = stream;
   a.geom = g;
   memcpy(a.q.q, ctx->q, sizeof a.q.q);
+  a.qs = ctx->qs;
+  a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
   const uint32_t resident = uint32_t(ctx->cu_count) * uint32_t(ctx->blocks_per_cu);
   a.grid = g.total_tiles < resident ? g.total_tiles : resident;
   if (a.grid == 0) a.grid = 1;
@@ -157,6 +172,25 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   a.state = ctx->d_state;
   D2PC_HIP(ctx, launch_compact(a));
   return D2PC_OK;
+}
+
+// Does Q have the structure cv::stereoRectify produces (hpp:104)?
+//   [1 0 0 cx; 0 1 0 cy; 0 0 0 f; 0 0 a b], zeros being +0.0 bit patterns.
+// Then the nine products with +0.0 / 1.0 are exact and the specialised kernel
+// returns bit-identical results (see reproject(QK_STEREO) in d2pc_kernels.hip).
+void classify_q(d2pc_ctx *ctx) {
+  const double *q = ctx->q;
+  auto pz = [](double x) { uint64_t b; memcpy(&b, &x, 8); return b == 0; };
+  const bool stereo = q[0] == 1.0 && q[5] == 1.0 && pz(q[1]) && pz(q[2]) && pz(q[4]) && pz(q[6]) && pz(q[8]) &&
+                      pz(q[9]) && pz(q[10]) && pz(q[12]) && pz(q[13]);
+  ctx->q_kind = stereo ? QK_STEREO : QK_GENERAL;
+  // the row constants as the general evaluation forms them: q_3 + (+0.0)
+  volatile double z = 0.0;
+  ctx->qs.cx = q[3] + z;
+  ctx->qs.cy = q[7] + z;
+  ctx->qs.f = q[11] + z;
+  ctx->qs.a = q[14];
+  ctx->qs.b = q[15] + z;
 }
 
 bool stream_is_capturing(hipStream_t s) {
@@ -278,6 +312,7 @@ int d2pc_set_q(d2pc_ctx *ctx, const double q[16]) {
   if (!q) return fail(ctx, D2PC_ERR_INVALID_ARG, "q is null");
   memcpy(ctx->q, q, sizeof ctx->q);  // bit copy: keeps -0.0 in Q[3][3]
   ctx->have_q = true;
+  classify_q(ctx);
   return D2PC_OK;
 }
 
@@ -328,6 +363,7 @@ int d2pc_import_calibration(d2pc_ctx *ctx, const void *blob, size_t bytes) {
     return fail(ctx, D2PC_ERR_INVALID_ARG, "calibration blob carries border %d mode %d", tail[0], tail[1]);
   memcpy(ctx->q, b, 128);
   ctx->have_q = true;
+  classify_q(ctx);
   ctx->cfg.border = tail[0];
   ctx->cfg.mode = tail[1];
   return D2PC_OK;
@@ -366,6 +402,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   if (!strcmp(key, "pxt_parity") && tile_shape_supported(value)) ctx->pxt_parity = value;
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 64) ctx->blocks_per_cu = value;
+  else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
   return D2PC_OK;
 }
@@ -373,16 +410,11 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
 int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
-  Geom g;
-  int st = make_geom(ctx, D2PC_DTYPE_F32, 1.f, width, height, size_t(width) * 4, size_t(width) * 4 * height, n_frames,
-                     d2pc_roi_points(width, height, ctx->cfg.border), ctx->pxt_compact, &g);
+  Geom g;  // the smallest supported tile (pxt = 4) gives the largest state
+  int st = make_geom(ctx, D2PC_DTYPE_U8, 1.f, width, height, size_t(width), size_t(width) * height, n_frames,
+                     d2pc_roi_points(width, height, ctx->cfg.border), 4, &g);
   if (st != D2PC_OK) return st;
-  // the smallest supported tile gives the largest state
-  Geom g4 = g;
-  g4.tile_px = 256u * 4u;
-  g4.tiles_per_frame = (g.roi_n + g4.tile_px - 1) / g4.tile_px;
-  g4.groups_per_frame = (g4.tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
-  return grow(ctx, &ctx->d_state, &ctx->state_cap, compact_state_bytes(g4));
+  return grow(ctx, &ctx->d_state, &ctx->state_cap, compact_state_bytes(g));
 }
 
 int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scale, int width, int height,
@@ -413,7 +445,7 @@ int d2pc_check_async_error(d2pc_ctx *ctx) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
   if (!ctx->d_state) return D2PC_OK;
   DeviceGuard guard(ctx->device);
-  CompactHeader h;
+  StateHeader h;
   D2PC_HIP(ctx, hipMemcpy(&h, ctx->d_state, sizeof h, hipMemcpyDeviceToHost));
   if (h.timeout) return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
   return D2PC_OK;
@@ -440,7 +472,10 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int wi
   if (!out_points) return fail(ctx, D2PC_ERR_INVALID_ARG, "out_points is null");
   if (!compact && capacity < g.roi_n)
     return fail(ctx, D2PC_ERR_CAPACITY, "capacity %zu < %u ROI points", capacity, g.roi_n);
-  g.row_stride = pitch;
+  // the caller's stride is validated above; the kernel sees the packed copy
+  if ((st = make_geom(ctx, dtype, scale, width, height, pitch, 0, 1, 0, compact ? ctx->pxt_compact : ctx->pxt_parity,
+                      &g)) != D2PC_OK)
+    return st;
   if ((st = grow(ctx, &ctx->d_in, &ctx->in_cap, pitch * size_t(height))) != D2PC_OK) return st;
   if ((st = grow(ctx, &ctx->d_out, &ctx->out_cap, size_t(g.roi_n) * 16)) != D2PC_OK) return st;
   if (out_index && (st = grow(ctx, &ctx->d_idx, &ctx->idx_cap, size_t(g.roi_n) * 4)) != D2PC_OK) return st;

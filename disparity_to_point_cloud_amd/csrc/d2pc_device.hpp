@@ -14,16 +14,17 @@
 
 namespace d2pc {
 
+constexpr int kBlock = 256;  // threads per workgroup (4 waves of 64)
+
 // ---- exact unsigned division by a launch-time constant --------------------
 // Granlund-Montgomery round-up method: q = (t + ((n - t) >> s1)) >> s2 with
 // t = mulhi(m, n); exact for every 32-bit n and every 1 <= d < 2^32.
 struct FastDiv {
-  uint32_t m, s1, s2, d;
+  uint32_t m, s1, s2;
 };
 
 inline FastDiv make_fastdiv(uint32_t d) {
   FastDiv f;
-  f.d = d;
   uint32_t l = 0;
   while (l < 32 && (uint64_t(1) << l) < d) ++l;  // l = ceil(log2 d)
   f.m = uint32_t(((uint64_t(1) << 32) * ((uint64_t(1) << l) - d)) / d + 1);
@@ -39,13 +40,15 @@ __host__ __device__ inline uint32_t fdiv(uint32_t n, const FastDiv &f) {
 
 // ---- launch geometry (kernarg; lives in SGPRs) ----------------------------
 struct Geom {
-  uint32_t width, height, border;
-  uint32_t roi_w, roi_h, roi_n;       // ROI size; roi_n = roi_w*roi_h points
-  uint32_t tile_px;                   // ROI pixels per tile (= BLOCK*PXT)
+  uint32_t width, border;
+  uint32_t roi_w, roi_n;              // ROI width; roi_n = ROI points per frame
   uint32_t tiles_per_frame, n_frames, total_tiles;
   uint32_t groups_per_frame;          // compaction: ceil(tiles_per_frame/64)
+  uint32_t row_stride;                // bytes between image rows (< 2^32)
+  uint32_t last_off;                  // byte offset of the frame's last ROI pixel
+  uint32_t step_v, step_u;            // kBlock = step_v*roi_w + step_u
+  uint32_t frame_state_stride;        // compaction: bytes of state per frame
   FastDiv div_roi_w, div_tpf;
-  uint64_t row_stride;                // bytes between image rows
   uint64_t in_frame_stride;           // bytes between frames
   uint64_t out_frame_stride;          // points between frames' outputs
   float scale;                        // U8/U16 decode: d = (float)raw*scale
@@ -58,17 +61,30 @@ struct QMat {
   double q[16];
 };
 
-enum : int { DT_F32 = 0, DT_U8 = 1, DT_U16 = 2 };
-
-// Compaction hand-off state (zeroed by a memset node before every launch).
-struct CompactHeader {
-  uint32_t ticket;        // single-pass: next tile to hand out
-  uint32_t timeout;       // set to 1 if a bounded spin expired
-  uint32_t pad[14];       // keep the header on its own 64-byte line
+// The structure cv::stereoRectify always produces (hpp:104):
+//   [1 0 0 cx; 0 1 0 cy; 0 0 0 f; 0 0 a b]   (zeros are +0.0, ones are 1.0)
+// lets the kernel drop nine multiply-adds per pixel with bit-identical
+// results: X = (u + cx)/W, Y = (v + cy)/W, Z = f/W, W = a*d + b.
+struct QStereo {
+  double cx, cy, f, a, b;  // cx = q03 + 0.0, cy = q13 + 0.0, f = q23 + 0.0, b = q33 + 0.0
 };
 
+enum : int { DT_F32 = 0, DT_U8 = 1, DT_U16 = 2 };
+enum : int { QK_GENERAL = 0, QK_STEREO = 1 };
+
+// ---- compaction state (zeroed by a memset node before every launch) -------
+//   [StateHeader 64 B][frame 0 state][frame 1 state]...
+//   frame state (frame_state_stride bytes, 256-B aligned):
+//     [ticket u32 on its own 64-B line][group_acc u64 x groups][granule u64 x tiles]
+//   group_acc = (tiles arrived << 32) | sum of their point counts
+//   granule   = kGranuleTag | point count of one tile
+struct StateHeader {
+  uint32_t timeout;       // set to 1 if a bounded spin expired
+  uint32_t pad[15];
+};
+constexpr uint32_t kFrameTicketBytes = 64;
 constexpr uint64_t kGranuleTag = uint64_t(1) << 63;
 constexpr int kGroupTiles = 64;         // tiles per counting group
-constexpr uint32_t kSpinLimit = 1u << 22;
+constexpr uint32_t kSpinLimit = 1u << 20;
 
 }  // namespace d2pc

@@ -5,14 +5,16 @@
 // Design (HBM-bound streaming map, ~1 flop/byte; MFMA does not apply):
 //  * Work is indexed by OUTPUT point, flat over the frame's ROI, so every
 //    wave-level store is one contiguous, 1-KiB, 16-B-per-lane write of final
-//    PointCloud2 bytes; a tile is BLOCK*PXT consecutive ROI pixels.
+//    PointCloud2 bytes; a tile is 256*PXT consecutive ROI pixels.
 //  * Disparity is read once with coalesced per-lane dword loads (64 lanes =
-//    256 contiguous bytes; ROI rows wrap inside a tile through an exact
-//    multiply-high division, no per-row tails).
+//    256 contiguous bytes); ROI rows wrap inside a tile: one exact
+//    multiply-high division per thread and tile, then (u,v) are stepped.
 //  * Q and the geometry are kernel arguments: they sit in SGPRs for the whole
 //    kernel (cheaper than LDS: no ds_read, no bank traffic, no barrier).
 //  * Arithmetic follows OpenCV's double-precision evaluation: fp64 FMA chain
 //    for the four row products, one IEEE fp64 reciprocal, one cast to fp32.
+//    When Q has the structure cv::stereoRectify produces (QK_STEREO) the
+//    multiplications by its exact zeros and ones are dropped -- bit-identical.
 //  * COMPACT mode: wave ballot + mbcnt ranks, LDS scan over the block's
 //    (slot, wave) counts, and a two-level counted prefix across tiles
 //    (64-bit {arrivals,sum} group accumulators + tagged per-tile granules)
@@ -28,32 +30,64 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // per-pixel pieces
 // --------------------------------------------------------------------------
 template <int DT>
-__device__ __forceinline__ float load_disparity(const uint8_t *frame, const Geom &g, uint32_t v, uint32_t u) {
-  const uint8_t *row = frame + uint64_t(v) * g.row_stride;
+__device__ __forceinline__ float load_disparity(const uint8_t *frame, uint32_t byte_off, float scale) {
+  // `frame` is wave-uniform, `byte_off` a 32-bit per-lane offset: one
+  // global_load with an SGPR base.  Read once => nontemporal.
   if constexpr (DT == DT_F32) {
-    return __builtin_nontemporal_load(reinterpret_cast<const float *>(row) + u);
+    return __builtin_nontemporal_load(reinterpret_cast<const float *>(frame + byte_off));
   } else if constexpr (DT == DT_U8) {
     // cpp:61 convertTo(CV_32FC1, scale): product formed in fp32
-    return __fmul_rn(float(__builtin_nontemporal_load(row + u)), g.scale);
+    return __fmul_rn(float(__builtin_nontemporal_load(frame + byte_off)), scale);
   } else {
-    return __fmul_rn(float(__builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(row) + u)), g.scale);
+    return __fmul_rn(float(__builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(frame + byte_off))), scale);
   }
 }
+
+template <int DT>
+__device__ __forceinline__ uint32_t elem_bytes() {
+  return DT == DT_F32 ? 4u : DT == DT_U16 ? 2u : 1u;
+}
+
+template <int QK>
+struct QArg;
+template <>
+struct QArg<QK_GENERAL> {
+  QMat m;
+};
+template <>
+struct QArg<QK_STEREO> {
+  QStereo s;
+};
 
 // cpp:63-64  [X Y Z W] = Q.(u,v,d,1); (X/W, Y/W, Z/W) evaluated in fp64 with
 // the association of OpenCV 2.4's loop: (row term + u*q_0) + d*q_2, then
 // iW = 1./W and num*iW, one cast to fp32 at the end.
-__device__ __forceinline__ void reproject(const QMat &Q, uint32_t u, uint32_t v, float d, float &X, float &Y,
-                                          float &Z) {
+__device__ __forceinline__ void reproject(const QArg<QK_GENERAL> &A, uint32_t u, uint32_t v, float d, float &X,
+                                          float &Y, float &Z) {
+  const double *q = A.m.q;
   const double du = double(u), dv = double(v), dd = double(d);
-  const double nx = fma(Q.q[2], dd, fma(Q.q[0], du, fma(Q.q[1], dv, Q.q[3])));
-  const double ny = fma(Q.q[6], dd, fma(Q.q[4], du, fma(Q.q[5], dv, Q.q[7])));
-  const double nz = fma(Q.q[10], dd, fma(Q.q[8], du, fma(Q.q[9], dv, Q.q[11])));
-  const double nw = fma(Q.q[14], dd, fma(Q.q[12], du, fma(Q.q[13], dv, Q.q[15])));
+  const double nx = fma(q[2], dd, fma(q[0], du, fma(q[1], dv, q[3])));
+  const double ny = fma(q[6], dd, fma(q[4], du, fma(q[5], dv, q[7])));
+  const double nz = fma(q[10], dd, fma(q[8], du, fma(q[9], dv, q[11])));
+  const double nw = fma(q[14], dd, fma(q[12], du, fma(q[13], dv, q[15])));
   const double iw = 1.0 / nw;
   X = float(nx * iw);
   Y = float(ny * iw);
   Z = float(nz * iw);
+}
+
+// Same evaluation with Q = [1 0 0 cx; 0 1 0 cy; 0 0 0 f; 0 0 a b]: the
+// products with +0.0 and 1.0 are exact, so only the sums that can round
+// remain.  A non-finite d makes every coordinate NaN in the general form
+// (0*inf), reproduced here by poisoning d before W is formed.
+__device__ __forceinline__ void reproject(const QArg<QK_STEREO> &A, uint32_t u, uint32_t v, float d, float &X,
+                                          float &Y, float &Z) {
+  const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
+  const double nw = fma(A.s.a, double(dsel), A.s.b);
+  const double iw = 1.0 / nw;
+  X = float((double(u) + A.s.cx) * iw);
+  Y = float((double(v) + A.s.cy) * iw);
+  Z = float(A.s.f * iw);
 }
 
 __device__ __forceinline__ bool point_is_valid(float X, float Y, float Z, float d, float min_disparity) {
@@ -62,48 +96,91 @@ __device__ __forceinline__ bool point_is_valid(float X, float Y, float Z, float 
   return (int(fabsf(X) < inf) & int(fabsf(Y) < inf) & int(fabsf(Z) < inf) & int(!(d <= min_disparity))) != 0;
 }
 
-__device__ __forceinline__ void store_point(float4 *dst, float X, float Y, float Z) {
-  // pcl::PointXYZ = {x,y,z,1.0f} (cpp:74); written once, never re-read here
+__device__ __forceinline__ void store_point(float4 *frame_out, uint32_t point, float X, float Y, float Z) {
+  // pcl::PointXYZ = {x,y,z,1.0f} (cpp:74): one global_store_dwordx4 with an
+  // SGPR base and a 32-bit byte offset (host guarantees roi_n <= 2^28).
   const v4f p = {X, Y, Z, 1.0f};
-  __builtin_nontemporal_store(p, reinterpret_cast<v4f *>(dst));  // one global_store_dwordx4 nt
+  *reinterpret_cast<v4f *>(reinterpret_cast<uint8_t *>(frame_out) + (point << 4)) = p;
+}
+
+__device__ __forceinline__ void store_index(uint32_t *frame_idx, uint32_t point, uint32_t pix) {
+  *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(frame_idx) + (point << 2)) = pix;
+}
+
+// ROI coordinates of the thread's pixel in slot 0 of a tile, then stepped by
+// kBlock pixels per slot: kBlock = step_v*roi_w + step_u.
+struct Walker {
+  uint32_t u, v;  // ROI-relative column / row
+  __device__ __forceinline__ Walker(const Geom &g, uint32_t i0) {
+    v = fdiv(i0, g.div_roi_w);
+    u = i0 - v * g.roi_w;
+  }
+  __device__ __forceinline__ void step(const Geom &g) {
+    u += g.step_u;
+    v += g.step_v;
+    if (u >= g.roi_w) {
+      u -= g.roi_w;
+      ++v;
+    }
+  }
+};
+
+// Loads + reprojects the PXT pixels of one thread.  Loads are issued first
+// (PXT independent dword loads in flight), arithmetic second.
+template <int DT, int QK, int PXT>
+struct TileRegs {
+  float X[PXT], Y[PXT], Z[PXT], d[PXT];
+  uint32_t pix[PXT];  // source pixel index v*W+u (image coordinates)
+};
+
+template <int DT, int QK, int PXT>
+__device__ __forceinline__ void tile_compute(TileRegs<DT, QK, PXT> &r, const uint8_t *fin, const Geom &g,
+                                             const QArg<QK> &Q, uint32_t base, uint32_t tid) {
+  uint32_t uu[PXT], vv[PXT];
+  Walker w(g, base + tid);
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    uu[k] = w.u + g.border;
+    vv[k] = w.v + g.border;
+    // byte offsets grow with the ROI index, so clamping to the last ROI
+    // pixel keeps the tail slots of a frame's last tile in bounds without
+    // predicating the loads (their results are never stored)
+    const uint32_t off = vv[k] * g.row_stride + uu[k] * elem_bytes<DT>();
+    r.d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
+    w.step(g);
+  }
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    reproject(Q, uu[k], vv[k], r.d[k], r.X[k], r.Y[k], r.Z[k]);
+    r.pix[k] = vv[k] * g.width + uu[k];
+  }
 }
 
 // --------------------------------------------------------------------------
 // K1: PARITY mode -- every ROI pixel, reference order, nothing filtered.
 // --------------------------------------------------------------------------
-template <int DT, int BLOCK, int PXT>
-__global__ __launch_bounds__(BLOCK) void k_reproject_pack(const uint8_t *__restrict__ disp,
-                                                          float4 *__restrict__ out,
-                                                          uint32_t *__restrict__ out_index,
-                                                          uint32_t *__restrict__ counts, const Geom g,
-                                                          const QMat Q) {
+template <int DT, int QK, int PXT>
+__global__ __launch_bounds__(kBlock) void k_reproject_pack(const uint8_t *__restrict__ disp,
+                                                           float4 *__restrict__ out,
+                                                           uint32_t *__restrict__ out_index,
+                                                           uint32_t *__restrict__ counts, const Geom g,
+                                                           const QArg<QK> Q) {
   const uint32_t tid = threadIdx.x;
   for (uint32_t t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
     const uint32_t f = fdiv(t, g.div_tpf);
     const uint32_t lt = t - f * g.tiles_per_frame;
     const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
     float4 *fout = out + uint64_t(f) * g.out_frame_stride;
-    const uint32_t base = lt * uint32_t(BLOCK * PXT);
-
-    float d[PXT];
-    uint32_t uu[PXT], vv[PXT];
+    uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
+    const uint32_t base = lt * uint32_t(kBlock * PXT);
+    TileRegs<DT, QK, PXT> r;
+    tile_compute<DT, QK, PXT>(r, fin, g, Q, base, tid);
 #pragma unroll
     for (int k = 0; k < PXT; ++k) {
-      const uint32_t i = base + uint32_t(k * BLOCK) + tid;
-      const uint32_t ic = i < g.roi_n ? i : g.roi_n - 1;  // keep tail loads in bounds
-      const uint32_t rv = fdiv(ic, g.div_roi_w);
-      uu[k] = ic - rv * g.roi_w + g.border;
-      vv[k] = rv + g.border;
-      d[k] = load_disparity<DT>(fin, g, vv[k], uu[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < PXT; ++k) {
-      const uint32_t i = base + uint32_t(k * BLOCK) + tid;
-      float X, Y, Z;
-      reproject(Q, uu[k], vv[k], d[k], X, Y, Z);
+      const uint32_t i = base + uint32_t(k * kBlock) + tid;
       if (i < g.roi_n) {
-        store_point(fout + i, X, Y, Z);
-        if (out_index) __builtin_nontemporal_store(vv[k] * g.width + uu[k], out_index + uint64_t(f) * g.out_frame_stride + i);
+        store_point(fout, i, r.X[k], r.Y[k], r.Z[k]);
+        if (fidx) store_index(fidx, i, r.pix[k]);
       }
     }
     if (counts && lt == 0 && tid == 0) counts[f] = g.roi_n;
@@ -126,10 +203,22 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
   return x;
 }
 
+// Validity ballots of a computed tile, one 64-bit wave mask per slot.
+template <int DT, int QK, int PXT>
+__device__ __forceinline__ void tile_ballots(const TileRegs<DT, QK, PXT> &r, const Geom &g, uint32_t base,
+                                             uint32_t tid, uint64_t (&mask)[PXT]) {
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    const uint32_t i = base + uint32_t(k * kBlock) + tid;
+    const bool ok = (i < g.roi_n) && point_is_valid(r.X[k], r.Y[k], r.Z[k], r.d[k], g.min_disparity);
+    mask[k] = __ballot(ok);
+  }
+}
+
 // Exclusive offsets of every (slot, wave) cell of a block in row-major
 // (slot-major, wave-minor) order == pixel order inside the tile.
-// s_cnt[k*WAVES + w] holds the wave's popcount for slot k.  Returns the
-// exclusive scan in lanes 0..PXT*WAVES-1 and the tile total in `total`.
+// s_cnt[k*4 + w] holds the wave's popcount for slot k.  Returns the
+// exclusive scan in lanes 0..CELLS-1 and the tile total in `total`.
 template <int CELLS>
 __device__ __forceinline__ uint32_t scan_cells(const uint32_t *s_cnt, uint32_t lane, uint32_t &total) {
   static_assert(CELLS <= 64, "one wave scans all cells");
@@ -144,110 +233,94 @@ __device__ __forceinline__ uint32_t scan_cells(const uint32_t *s_cnt, uint32_t l
   return incl - c;
 }
 
-// Sum of the point counts of all tiles of frame f that precede local tile lt:
-// full groups via the group accumulators, the partial group via tile granules.
-// WAIT = true (single pass): spin, bounded, until every predecessor has
-// published; WAIT = false (two-pass scatter): values are final already.
-template <bool WAIT>
-__device__ __forceinline__ uint32_t prefix_before(const uint64_t *group_acc, const uint64_t *granules,
-                                                  CompactHeader *hdr, const Geom &g, uint32_t f, uint32_t lt,
-                                                  uint32_t lane) {
+struct FrameState {
+  uint32_t *ticket;
+  uint64_t *group_acc;
+  uint64_t *granules;
+  __device__ __forceinline__ FrameState(uint8_t *state, const Geom &g, uint32_t f) {
+    uint8_t *fs = state + sizeof(StateHeader) + uint64_t(f) * g.frame_state_stride;
+    ticket = reinterpret_cast<uint32_t *>(fs);
+    group_acc = reinterpret_cast<uint64_t *>(fs + kFrameTicketBytes);
+    granules = group_acc + g.groups_per_frame;
+  }
+};
+
+__device__ __forceinline__ void backoff(uint32_t spins) {
+  // 64 .. ~2000 clocks between polls; pollers must not crowd the memory
+  // channel the publishers' atomics go through
+  const uint32_t n = spins < 5 ? (1u << spins) : 32u;
+  for (uint32_t j = 0; j < n; ++j) __builtin_amdgcn_s_sleep(1);
+}
+
+// Waits (WAIT) until the 64-bit word at p satisfies `ready`, and returns it.
+// First look is a normal cached load: a word that already carries its
+// completion mark (all 64 arrivals / the granule tag) is final, so a cached
+// copy of it is as good as memory; only words not yet complete are re-read
+// with agent-scope (coherent) loads, with back-off.
+template <bool WAIT, class Ready>
+__device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, StateHeader *hdr, uint32_t lane,
+                                                 Ready ready) {
   using gu64 = __attribute__((address_space(1))) const uint64_t;
+  uint64_t v = 0;
+  if constexpr (!WAIT) {
+    if (on) v = *p;
+    return v;
+  } else {
+    if (on) v = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    bool ok = !on || ready(v);
+    uint32_t spins = 0;
+    while (!__all(ok)) {
+      backoff(spins);
+      if (!ok) {
+        v = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ready(v);
+      }
+      if (++spins > kSpinLimit) {
+        if (lane == 0) __hip_atomic_store(&hdr->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    return v;
+  }
+}
+
+// Sum of the point counts of all tiles of the frame that precede local tile
+// lt: complete groups via the group accumulators, the own (partial) group via
+// tile granules.  WAIT = true (single pass): bounded wait until every
+// predecessor has published; WAIT = false (two-pass): values are final.
+template <bool WAIT>
+__device__ __forceinline__ uint32_t prefix_before(const FrameState &fs, StateHeader *hdr, uint32_t lt,
+                                                  uint32_t lane) {
   const uint32_t grp = lt / kGroupTiles;
-  const uint64_t *ga = group_acc + uint64_t(f) * g.groups_per_frame;
-  const uint64_t *tg = granules + uint64_t(f) * g.tiles_per_frame;
   uint32_t sum = 0;
-  // groups 0..grp-1 are complete groups of kGroupTiles tiles each
-  for (uint32_t g0 = 0; g0 < grp; g0 += 64) {
+  for (uint32_t g0 = 0; g0 < grp; g0 += 64) {  // groups 0..grp-1 hold kGroupTiles tiles each
     const uint32_t gi = g0 + lane;
     const bool on = gi < grp;
-    uint64_t v = 0;
-    if constexpr (WAIT) {
-      uint32_t spins = 0;
-      for (;;) {
-        if (on) v = __hip_atomic_load((gu64 *)(ga + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ready = !on || uint32_t(v >> 32) == uint32_t(kGroupTiles);
-        if (__all(ready)) break;
-        if (++spins > kSpinLimit) {
-          if (lane == 0) __hip_atomic_store(&hdr->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-    } else {
-      if (on) v = ga[gi];
-    }
+    const uint64_t v = read_counted<WAIT>(fs.group_acc + gi, on, hdr, lane,
+                                          [](uint64_t x) { return uint32_t(x >> 32) == uint32_t(kGroupTiles); });
     sum += on ? uint32_t(v) : 0u;
   }
-  // tiles grp*64 .. lt-1 of the own group (< 64 of them)
-  {
+  {  // tiles grp*64 .. lt-1 of the own group (< 64 of them)
     const uint32_t ti = grp * kGroupTiles + lane;
     const bool on = ti < lt;
-    uint64_t v = 0;
-    if constexpr (WAIT) {
-      uint32_t spins = 0;
-      for (;;) {
-        if (on) v = __hip_atomic_load((gu64 *)(tg + ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ready = !on || (v & kGranuleTag) != 0;
-        if (__all(ready)) break;
-        if (++spins > kSpinLimit) {
-          if (lane == 0) __hip_atomic_store(&hdr->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-    } else {
-      if (on) v = tg[ti];
-    }
+    const uint64_t v = read_counted<WAIT>(fs.granules + ti, on, hdr, lane,
+                                          [](uint64_t x) { return (x & kGranuleTag) != 0; });
     sum += on ? uint32_t(v) : 0u;
   }
   return wave_sum(sum);
 }
 
-// One tile of COMPACT work held in registers.
-template <int DT, int BLOCK, int PXT>
-struct TileRegs {
-  float X[PXT], Y[PXT], Z[PXT];
-  uint32_t pix[PXT];   // source pixel index v*W+u
-  uint64_t mask[PXT];  // wave ballot of validity per slot
-};
-
-template <int DT, int BLOCK, int PXT>
-__device__ __forceinline__ void tile_compute(TileRegs<DT, BLOCK, PXT> &r, const uint8_t *fin, const Geom &g,
-                                             const QMat &Q, uint32_t base, uint32_t tid) {
-  float d[PXT];
-  uint32_t uu[PXT], vv[PXT];
+template <int DT, int QK, int PXT>
+__device__ __forceinline__ void tile_scatter(const TileRegs<DT, QK, PXT> &r, const uint64_t (&mask)[PXT],
+                                             float4 *fout, uint32_t *fidx, uint32_t tile_prefix,
+                                             uint32_t cell_excl, uint32_t wave, uint32_t lane) {
 #pragma unroll
   for (int k = 0; k < PXT; ++k) {
-    const uint32_t i = base + uint32_t(k * BLOCK) + tid;
-    const uint32_t ic = i < g.roi_n ? i : g.roi_n - 1;
-    const uint32_t rv = fdiv(ic, g.div_roi_w);
-    uu[k] = ic - rv * g.roi_w + g.border;
-    vv[k] = rv + g.border;
-    d[k] = load_disparity<DT>(fin, g, vv[k], uu[k]);
-  }
-#pragma unroll
-  for (int k = 0; k < PXT; ++k) {
-    const uint32_t i = base + uint32_t(k * BLOCK) + tid;
-    reproject(Q, uu[k], vv[k], d[k], r.X[k], r.Y[k], r.Z[k]);
-    r.pix[k] = vv[k] * g.width + uu[k];
-    const bool ok = (i < g.roi_n) && point_is_valid(r.X[k], r.Y[k], r.Z[k], d[k], g.min_disparity);
-    r.mask[k] = __ballot(ok);
-  }
-}
-
-template <int DT, int BLOCK, int PXT>
-__device__ __forceinline__ void tile_scatter(const TileRegs<DT, BLOCK, PXT> &r, float4 *fout, uint32_t *fidx,
-                                             uint32_t tile_prefix, uint32_t cell_excl, uint32_t wave,
-                                             uint32_t lane) {
-  constexpr int WAVES = BLOCK / 64;
-#pragma unroll
-  for (int k = 0; k < PXT; ++k) {
-    const uint32_t cell = __builtin_amdgcn_readlane(cell_excl, k * WAVES + int(wave));
-    const uint32_t pos = tile_prefix + cell + mbcnt64(r.mask[k]);
-    if ((r.mask[k] >> lane) & 1) {
-      store_point(fout + pos, r.X[k], r.Y[k], r.Z[k]);
-      if (fidx) __builtin_nontemporal_store(r.pix[k], fidx + pos);
+    const uint32_t cell = __builtin_amdgcn_readlane(cell_excl, k * (kBlock / 64) + int(wave));
+    const uint32_t pos = tile_prefix + cell + mbcnt64(mask[k]);
+    if ((mask[k] >> lane) & 1) {
+      store_point(fout, pos, r.X[k], r.Y[k], r.Z[k]);
+      if (fidx) store_index(fidx, pos, r.pix[k]);
     }
   }
 }
@@ -255,58 +328,62 @@ __device__ __forceinline__ void tile_scatter(const TileRegs<DT, BLOCK, PXT> &r, 
 // --------------------------------------------------------------------------
 // K2a/K2b: two-pass compaction (count -> scatter).  No in-launch hand-off.
 // --------------------------------------------------------------------------
-template <int DT, int BLOCK, int PXT>
-__global__ __launch_bounds__(BLOCK) void k_compact_count(const uint8_t *__restrict__ disp, uint64_t *group_acc,
-                                                         uint64_t *granules, const Geom g, const QMat Q) {
-  constexpr int WAVES = BLOCK / 64;
+template <int DT, int QK, int PXT>
+__global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restrict__ disp, uint8_t *state,
+                                                          const Geom g, const QArg<QK> Q) {
+  constexpr int WAVES = kBlock / 64;
   __shared__ uint32_t s_w[WAVES];
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (uint32_t t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
     const uint32_t f = fdiv(t, g.div_tpf);
     const uint32_t lt = t - f * g.tiles_per_frame;
-    TileRegs<DT, BLOCK, PXT> r;
-    tile_compute<DT, BLOCK, PXT>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, lt * uint32_t(BLOCK * PXT), tid);
+    const uint32_t base = lt * uint32_t(kBlock * PXT);
+    TileRegs<DT, QK, PXT> r;
+    uint64_t mask[PXT];
+    tile_compute<DT, QK, PXT>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, base, tid);
+    tile_ballots<DT, QK, PXT>(r, g, base, tid, mask);
     uint32_t c = 0;
 #pragma unroll
-    for (int k = 0; k < PXT; ++k) c += uint32_t(__popcll(r.mask[k]));
+    for (int k = 0; k < PXT; ++k) c += uint32_t(__popcll(mask[k]));
     if (lane == 0) s_w[wave] = c;
     __syncthreads();
     if (tid == 0) {
       uint32_t tot = 0;
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) tot += s_w[w];
-      granules[uint64_t(f) * g.tiles_per_frame + lt] = tot;
-      atomicAdd(reinterpret_cast<unsigned long long *>(group_acc + uint64_t(f) * g.groups_per_frame + lt / kGroupTiles),
-                (unsigned long long)tot);
+      const FrameState fs(state, g, f);
+      fs.granules[lt] = tot;
+      atomicAdd(reinterpret_cast<unsigned long long *>(fs.group_acc + lt / kGroupTiles), (unsigned long long)tot);
     }
     __syncthreads();
   }
 }
 
-template <int DT, int BLOCK, int PXT>
-__global__ __launch_bounds__(BLOCK) void k_compact_scatter(const uint8_t *__restrict__ disp,
-                                                           float4 *__restrict__ out,
-                                                           uint32_t *__restrict__ out_index,
-                                                           uint32_t *__restrict__ counts,
-                                                           const uint64_t *__restrict__ group_acc,
-                                                           const uint64_t *__restrict__ granules, const Geom g,
-                                                           const QMat Q) {
-  constexpr int WAVES = BLOCK / 64;
-  constexpr int CELLS = PXT * WAVES;
+template <int DT, int QK, int PXT>
+__global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__restrict__ disp,
+                                                            float4 *__restrict__ out,
+                                                            uint32_t *__restrict__ out_index,
+                                                            uint32_t *__restrict__ counts, uint8_t *state,
+                                                            const Geom g, const QArg<QK> Q) {
+  constexpr int CELLS = PXT * (kBlock / 64);
   __shared__ uint32_t s_cnt[CELLS];
   __shared__ uint32_t s_prefix;
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (uint32_t t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
     const uint32_t f = fdiv(t, g.div_tpf);
     const uint32_t lt = t - f * g.tiles_per_frame;
-    TileRegs<DT, BLOCK, PXT> r;
-    tile_compute<DT, BLOCK, PXT>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, lt * uint32_t(BLOCK * PXT), tid);
+    const uint32_t base = lt * uint32_t(kBlock * PXT);
+    TileRegs<DT, QK, PXT> r;
+    uint64_t mask[PXT];
+    tile_compute<DT, QK, PXT>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, base, tid);
+    tile_ballots<DT, QK, PXT>(r, g, base, tid, mask);
     if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < PXT; ++k) s_cnt[k * WAVES + wave] = uint32_t(__popcll(r.mask[k]));
+      for (int k = 0; k < PXT; ++k) s_cnt[k * (kBlock / 64) + wave] = uint32_t(__popcll(mask[k]));
     }
     if (wave == 0) {
-      const uint32_t p = prefix_before<false>(group_acc, granules, nullptr, g, f, lt, lane);
+      const FrameState fs(state, g, f);
+      const uint32_t p = prefix_before<false>(fs, nullptr, lt, lane);
       if (lane == 0) s_prefix = p;
     }
     __syncthreads();
@@ -315,144 +392,176 @@ __global__ __launch_bounds__(BLOCK) void k_compact_scatter(const uint8_t *__rest
     const uint32_t prefix = s_prefix;
     float4 *fout = out + uint64_t(f) * g.out_frame_stride;
     uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
-    tile_scatter<DT, BLOCK, PXT>(r, fout, fidx, prefix, excl, wave, lane);
+    tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane);
     if (counts && lt == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + total;
     __syncthreads();
   }
 }
 
 // --------------------------------------------------------------------------
-// K2: single-pass compaction.  Tiles are handed out by a ticket counter, so
-// every predecessor of a tile is already running (or done) when the tile
-// starts: waiting on predecessors' COUNTS cannot deadlock whatever the
-// dispatch order or residency.  A tile publishes its count right after its
-// own loads (it never waits before publishing), so there is no serial chain:
-// the wait is for the slowest predecessor's load, not for a scan to ripple.
+// K2: single-pass compaction.
+//  * A block serves ONE frame at a time (frame = blockIdx % n_frames), and
+//    takes that frame's tiles from the frame's own ticket counter: every
+//    predecessor of a tile is therefore already running (or done) when the
+//    tile starts, so waiting for predecessors' COUNTS cannot deadlock
+//    whatever the dispatch order or residency.  Per-frame counters keep the
+//    ticket atomics, and the words the waiters poll, spread over addresses.
+//  * A tile publishes its count right after its own loads (it never waits
+//    before publishing), so there is no serial chain: the wait is for the
+//    slowest predecessor's load, not for a scan to ripple through.
 // --------------------------------------------------------------------------
-template <int DT, int BLOCK, int PXT>
-__global__ __launch_bounds__(BLOCK) void k_compact_onepass(const uint8_t *__restrict__ disp,
-                                                           float4 *__restrict__ out,
-                                                           uint32_t *__restrict__ out_index,
-                                                           uint32_t *__restrict__ counts, CompactHeader *hdr,
-                                                           uint64_t *group_acc, uint64_t *granules, const Geom g,
-                                                           const QMat Q) {
+template <int DT, int QK, int PXT>
+__global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__restrict__ disp,
+                                                            float4 *__restrict__ out,
+                                                            uint32_t *__restrict__ out_index,
+                                                            uint32_t *__restrict__ counts, uint8_t *state,
+                                                            const Geom g, const QArg<QK> Q) {
   using gu64 = __attribute__((address_space(1))) uint64_t;
-  constexpr int WAVES = BLOCK / 64;
-  constexpr int CELLS = PXT * WAVES;
+  constexpr int CELLS = PXT * (kBlock / 64);
   __shared__ uint32_t s_cnt[CELLS];
   __shared__ uint32_t s_prefix;
   __shared__ uint32_t s_ticket[2];
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
 
-  if (tid == 0) s_ticket[1] = atomicAdd(&hdr->ticket, 1u);
-  __syncthreads();
-  uint32_t t = s_ticket[1];
-  uint32_t it = 0;
-  while (t < g.total_tiles) {
-    const uint32_t f = fdiv(t, g.div_tpf);
-    const uint32_t lt = t - f * g.tiles_per_frame;
-    TileRegs<DT, BLOCK, PXT> r;
-    tile_compute<DT, BLOCK, PXT>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, lt * uint32_t(BLOCK * PXT), tid);
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < PXT; ++k) s_cnt[k * WAVES + wave] = uint32_t(__popcll(r.mask[k]));
-    }
-    __syncthreads();
-    uint32_t total;
-    const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
-    uint32_t next_t = 0;
-    if (wave == 0) {
-      if (lane == 0) {
-        // publish: tagged granule (the data is the flag) + group accumulator
-        __hip_atomic_store((gu64 *)(granules + uint64_t(f) * g.tiles_per_frame + lt), kGranuleTag | total,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add((gu64 *)(group_acc + uint64_t(f) * g.groups_per_frame + lt / kGroupTiles),
-                               (uint64_t(1) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // take the NEXT ticket now: its latency hides under the wait below
-        next_t = atomicAdd(&hdr->ticket, 1u);
-      }
-      const uint32_t p = prefix_before<true>(group_acc, granules, hdr, g, f, lt, lane);
-      if (lane == 0) {
-        s_prefix = p;
-        s_ticket[it & 1] = next_t;
-      }
-    }
-    __syncthreads();
-    const uint32_t prefix = s_prefix;
-    t = s_ticket[it & 1];
-    ++it;
+  for (uint32_t f = blockIdx.x % g.n_frames; f < g.n_frames; f += gridDim.x) {
+    const FrameState fs(state, g, f);
+    const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
     float4 *fout = out + uint64_t(f) * g.out_frame_stride;
     uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
-    tile_scatter<DT, BLOCK, PXT>(r, fout, fidx, prefix, excl, wave, lane);
-    if (counts && lt == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + total;
+
+    if (tid == 0) s_ticket[0] = atomicAdd(fs.ticket, 1u);
+    __syncthreads();
+    uint32_t lt = s_ticket[0];
+    uint32_t it = 0;
+    while (lt < g.tiles_per_frame) {
+      // take the NEXT ticket first: its round trip hides under this tile
+      uint32_t next_lt = 0;
+      if (tid == 0) next_lt = atomicAdd(fs.ticket, 1u);
+
+      const uint32_t base = lt * uint32_t(kBlock * PXT);
+      TileRegs<DT, QK, PXT> r;
+      uint64_t mask[PXT];
+      tile_compute<DT, QK, PXT>(r, fin, g, Q, base, tid);
+      tile_ballots<DT, QK, PXT>(r, g, base, tid, mask);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < PXT; ++k) s_cnt[k * (kBlock / 64) + wave] = uint32_t(__popcll(mask[k]));
+      }
+      __syncthreads();
+      uint32_t total;
+      const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
+      if (wave == 0) {
+        if (lane == 0) {
+          // publish: tagged granule (the data is the flag) + group accumulator
+          __hip_atomic_store((gu64 *)(fs.granules + lt), kGranuleTag | total, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add((gu64 *)(fs.group_acc + lt / kGroupTiles), (uint64_t(1) << 32) | total,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t p = prefix_before<true>(fs, hdr, lt, lane);
+        if (lane == 0) {
+          s_prefix = p;
+          s_ticket[(it + 1) & 1] = next_lt;
+        }
+      }
+      __syncthreads();
+      const uint32_t prefix = s_prefix;
+      tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane);
+      if (counts && lt == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + total;
+      lt = s_ticket[(it + 1) & 1];
+      ++it;
+    }
+    __syncthreads();
   }
 }
 
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
-template <int DT, int BLOCK, int PXT>
+template <int QK>
+static QArg<QK> make_qarg(const LaunchArgs &a);
+template <>
+QArg<QK_GENERAL> make_qarg<QK_GENERAL>(const LaunchArgs &a) {
+  QArg<QK_GENERAL> r;
+  r.m = a.q;
+  return r;
+}
+template <>
+QArg<QK_STEREO> make_qarg<QK_STEREO>(const LaunchArgs &a) {
+  QArg<QK_STEREO> r;
+  r.s = a.qs;
+  return r;
+}
+
+template <int DT, int QK, int PXT>
 static hipError_t launch_parity_t(const LaunchArgs &a) {
-  hipLaunchKernelGGL((k_reproject_pack<DT, BLOCK, PXT>), dim3(a.grid), dim3(BLOCK), 0, a.stream,
+  hipLaunchKernelGGL((k_reproject_pack<DT, QK, PXT>), dim3(a.grid), dim3(kBlock), 0, a.stream,
                      static_cast<const uint8_t *>(a.disp), static_cast<float4 *>(a.out_points), a.out_index,
-                     a.counts, a.geom, a.q);
+                     a.counts, a.geom, make_qarg<QK>(a));
   return hipGetLastError();
 }
 
-template <int DT, int BLOCK, int PXT>
+template <int DT, int QK, int PXT>
 static hipError_t launch_compact_t(const LaunchArgs &a) {
   const uint8_t *disp = static_cast<const uint8_t *>(a.disp);
   float4 *out = static_cast<float4 *>(a.out_points);
+  uint8_t *state = static_cast<uint8_t *>(a.state);
   hipError_t e = hipMemsetAsync(a.state, 0, a.state_bytes, a.stream);
   if (e != hipSuccess) return e;
-  CompactHeader *hdr = static_cast<CompactHeader *>(a.state);
-  uint64_t *group_acc = reinterpret_cast<uint64_t *>(hdr + 1);
-  uint64_t *granules = group_acc + uint64_t(a.geom.n_frames) * a.geom.groups_per_frame;
   if (a.compact_algo == 1) {
-    hipLaunchKernelGGL((k_compact_count<DT, BLOCK, PXT>), dim3(a.grid), dim3(BLOCK), 0, a.stream, disp, group_acc,
-                       granules, a.geom, a.q);
-    hipLaunchKernelGGL((k_compact_scatter<DT, BLOCK, PXT>), dim3(a.grid), dim3(BLOCK), 0, a.stream, disp, out,
-                       a.out_index, a.counts, group_acc, granules, a.geom, a.q);
+    hipLaunchKernelGGL((k_compact_count<DT, QK, PXT>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, state, a.geom,
+                       make_qarg<QK>(a));
+    hipLaunchKernelGGL((k_compact_scatter<DT, QK, PXT>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, out,
+                       a.out_index, a.counts, state, a.geom, make_qarg<QK>(a));
   } else {
-    hipLaunchKernelGGL((k_compact_onepass<DT, BLOCK, PXT>), dim3(a.grid), dim3(BLOCK), 0, a.stream, disp, out,
-                       a.out_index, a.counts, hdr, group_acc, granules, a.geom, a.q);
+    // frame-static assignment: the grid is a multiple of n_frames, or smaller
+    uint32_t grid = a.grid;
+    if (grid >= a.geom.n_frames) grid -= grid % a.geom.n_frames;
+    hipLaunchKernelGGL((k_compact_onepass<DT, QK, PXT>), dim3(grid), dim3(kBlock), 0, a.stream, disp, out,
+                       a.out_index, a.counts, state, a.geom, make_qarg<QK>(a));
   }
   return hipGetLastError();
 }
 
-template <int BLOCK, int PXT>
+template <int QK, int PXT>
 static hipError_t dispatch_dtype(const LaunchArgs &a, bool compact) {
   switch (a.dtype) {
-    case DT_F32: return compact ? launch_compact_t<DT_F32, BLOCK, PXT>(a) : launch_parity_t<DT_F32, BLOCK, PXT>(a);
-    case DT_U8: return compact ? launch_compact_t<DT_U8, BLOCK, PXT>(a) : launch_parity_t<DT_U8, BLOCK, PXT>(a);
-    case DT_U16: return compact ? launch_compact_t<DT_U16, BLOCK, PXT>(a) : launch_parity_t<DT_U16, BLOCK, PXT>(a);
+    case DT_F32: return compact ? launch_compact_t<DT_F32, QK, PXT>(a) : launch_parity_t<DT_F32, QK, PXT>(a);
+    case DT_U8: return compact ? launch_compact_t<DT_U8, QK, PXT>(a) : launch_parity_t<DT_U8, QK, PXT>(a);
+    case DT_U16: return compact ? launch_compact_t<DT_U16, QK, PXT>(a) : launch_parity_t<DT_U16, QK, PXT>(a);
   }
   return hipErrorInvalidValue;
+}
+
+template <int PXT>
+static hipError_t dispatch_q(const LaunchArgs &a, bool compact) {
+  return a.q_kind == QK_STEREO ? dispatch_dtype<QK_STEREO, PXT>(a, compact)
+                               : dispatch_dtype<QK_GENERAL, PXT>(a, compact);
 }
 
 bool tile_shape_supported(int pxt) { return pxt == 4 || pxt == 8 || pxt == 16; }
 
+uint32_t frame_state_stride(uint32_t tiles_per_frame) {
+  const uint32_t groups = (tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
+  const uint64_t b = kFrameTicketBytes + uint64_t(groups + tiles_per_frame) * 8;
+  return uint32_t((b + 255) & ~uint64_t(255));
+}
+
 size_t compact_state_bytes(const Geom &g) {
-  size_t b = sizeof(CompactHeader) + (uint64_t(g.n_frames) * g.groups_per_frame + uint64_t(g.n_frames) * g.tiles_per_frame) * 8;
-  return (b + 15) & ~size_t(15);
+  return sizeof(StateHeader) + size_t(g.n_frames) * g.frame_state_stride;
 }
 
-hipError_t launch_parity(const LaunchArgs &a) {
+static hipError_t dispatch(const LaunchArgs &a, bool compact) {
   switch (a.pxt) {
-    case 4: return dispatch_dtype<256, 4>(a, false);
-    case 8: return dispatch_dtype<256, 8>(a, false);
-    case 16: return dispatch_dtype<256, 16>(a, false);
+    case 4: return dispatch_q<4>(a, compact);
+    case 8: return dispatch_q<8>(a, compact);
+    case 16: return dispatch_q<16>(a, compact);
   }
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_compact(const LaunchArgs &a) {
-  switch (a.pxt) {
-    case 4: return dispatch_dtype<256, 4>(a, true);
-    case 8: return dispatch_dtype<256, 8>(a, true);
-    case 16: return dispatch_dtype<256, 16>(a, true);
-  }
-  return hipErrorInvalidValue;
-}
+hipError_t launch_parity(const LaunchArgs &a) { return dispatch(a, false); }
+hipError_t launch_compact(const LaunchArgs &a) { return dispatch(a, true); }
 
 }  // namespace d2pc

@@ -23,10 +23,13 @@ struct LaunchArgs {
   uint32_t grid = 1;
   hipStream_t stream = nullptr;
   Geom geom{};
+  int q_kind = QK_GENERAL;        // QK_STEREO when Q has stereoRectify's structure
   QMat q{};
+  QStereo qs{};
 };
 
 bool tile_shape_supported(int pxt);
+uint32_t frame_state_stride(uint32_t tiles_per_frame);
 size_t compact_state_bytes(const Geom &g);
 hipError_t launch_parity(const LaunchArgs &a);
 hipError_t launch_compact(const LaunchArgs &a);
