@@ -27,7 +27,7 @@ struct d2pc_ctx {
   int q_kind = QK_GENERAL;
   QStereo qs{};
   // tuning (d2pc_set_tuning); defaults from tools/tune.py on MI355X
-  int pxt_parity = 8, pxt_compact = 8;
+  int pxt_parity = 16, pxt_compact = 16;
   int blocks_per_cu = 16;
   int force_general_q = 0;
   // device scratch
@@ -152,6 +152,15 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   memcpy(a.q.q, ctx->q, sizeof a.q.q);
   a.qs = ctx->qs;
   a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
+  {
+    // bound on |u + cx|, |v + cy|, |f| over the frame, scaled by 2^-126: any
+    // |W| at least this large keeps every quotient below 2^126 < FLT_MAX
+    const double height = double((g.last_off / (g.row_stride ? g.row_stride : 1u)) + 1u);
+    const double mx = std::fmax(std::fabs(ctx->qs.cx), std::fabs(ctx->qs.cx + double(g.width)));
+    const double my = std::fmax(std::fabs(ctx->qs.cy), std::fabs(ctx->qs.cy + height));
+    const double m = std::fmax(std::fabs(ctx->qs.f), std::fmax(mx, my));
+    a.qs.w_safe = std::isfinite(m) ? std::ldexp(m, -126) : std::numeric_limits<double>::infinity();
+  }
   const uint32_t resident = uint32_t(ctx->cu_count) * uint32_t(ctx->blocks_per_cu);
   a.grid = g.total_tiles < resident ? g.total_tiles : resident;
   if (a.grid == 0) a.grid = 1;
@@ -162,7 +171,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   }
   if (!d_counts) return fail(ctx, D2PC_ERR_INVALID_ARG, "COMPACT mode needs a d_counts buffer");
   a.pxt = ctx->pxt_compact;
-  a.compact_algo = ctx->cfg.compact_algo == 1 ? 1 : 2;
+  a.compact_algo = ctx->cfg.compact_algo == 2 ? 2 : 1;  // default: two-pass (faster today, no spin-waits)
   a.state_bytes = compact_state_bytes(g);
   if (a.state_bytes > ctx->state_cap) {
     if (!allow_alloc) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "compaction state not reserved (call d2pc_reserve)");
@@ -451,6 +460,16 @@ int d2pc_check_async_error(d2pc_ctx *ctx) {
   return D2PC_OK;
 }
 
+#ifdef D2PC_DIAG
+// diagnostic build only: copy the 64-byte state header (phase timers) out
+int d2pc_debug_read_header(d2pc_ctx *ctx, void *out64) {
+  if (!ctx || !ctx->d_state) return D2PC_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  D2PC_HIP(ctx, hipMemcpy(out64, ctx->d_state, 64, hipMemcpyDeviceToHost));
+  return D2PC_OK;
+}
+#endif
+
 int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int width, int height,
                  size_t row_stride, void *out_points, uint32_t *out_index, size_t capacity, size_t *n_points) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
@@ -489,7 +508,7 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int wi
   if (compact) {
     D2PC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     D2PC_HIP(ctx, hipStreamSynchronize(s));
-    if (ctx->cfg.compact_algo != 1 && (st = d2pc_check_async_error(ctx)) != D2PC_OK) return st;
+    if (ctx->cfg.compact_algo == 2 && (st = d2pc_check_async_error(ctx)) != D2PC_OK) return st;
     n = ctx->h_counts[0];
     if (n > capacity) return fail(ctx, D2PC_ERR_CAPACITY, "capacity %zu < %zu valid points", capacity, n);
   }

@@ -67,6 +67,7 @@ struct QMat {
 // results: X = (u + cx)/W, Y = (v + cy)/W, Z = f/W, W = a*d + b.
 struct QStereo {
   double cx, cy, f, a, b;  // cx = q03 + 0.0, cy = q13 + 0.0, f = q23 + 0.0, b = q33 + 0.0
+  double w_safe;           // |W| >= w_safe  =>  every coordinate is a finite float (per launch)
 };
 
 enum : int { DT_F32 = 0, DT_U8 = 1, DT_U16 = 2 };
@@ -80,7 +81,9 @@ enum : int { QK_GENERAL = 0, QK_STEREO = 1 };
 //   granule   = kGranuleTag | point count of one tile
 struct StateHeader {
   uint32_t timeout;       // set to 1 if a bounded spin expired
-  uint32_t pad[15];
+  uint32_t pad;
+  // diagnostic build only (-DD2PC_DIAG): shader-clock sums over all tiles
+  unsigned long long diag[7];  // tiles, spins, t_compute, t_ticket, t_wait, t_scatter, t_total
 };
 constexpr uint32_t kFrameTicketBytes = 64;
 constexpr uint64_t kGranuleTag = uint64_t(1) << 63;

@@ -107,6 +107,28 @@ __device__ __forceinline__ void store_index(uint32_t *frame_idx, uint32_t point,
   *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(frame_idx) + (point << 2)) = pix;
 }
 
+// Exact validity of a STEREO-structured point WITHOUT evaluating it (used by
+// the two-pass count kernel, which only needs the predicate):
+//   |W| >= w_safe  =>  |num/W| <= 2^126 for every numerator of the frame, so
+//                      X, Y, Z are finite floats            -> valid
+//   W == 0 or NaN  =>  iW is inf/NaN, Z = f*iW is not finite -> invalid
+//   0 < |W| < w_safe (never seen with real calibrations): evaluate fully.
+// w_safe = 2^-126 * max|numerator| is formed on the host (QStereo::w_safe).
+__device__ __forceinline__ bool stereo_point_valid(const QArg<QK_STEREO> &A, uint32_t u, uint32_t v, float d,
+                                                   float min_disparity) {
+  const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
+  const double nw = fma(A.s.a, double(dsel), A.s.b);
+  const double aw = fabs(nw);
+  bool ok = aw >= A.s.w_safe;  // false for NaN
+  if (!ok && aw > 0.0) {       // tiny non-zero W: decide by the real arithmetic
+    float X, Y, Z;
+    reproject(A, u, v, d, X, Y, Z);
+    const float inf = __builtin_huge_valf();
+    ok = (fabsf(X) < inf) && (fabsf(Y) < inf) && (fabsf(Z) < inf);
+  }
+  return ok && !(d <= min_disparity);
+}
+
 // ROI coordinates of the thread's pixel in slot 0 of a tile, then stepped by
 // kBlock pixels per slot: kBlock = step_v*roi_w + step_u.
 struct Walker {
@@ -259,7 +281,7 @@ __device__ __forceinline__ void backoff(uint32_t spins) {
 // with agent-scope (coherent) loads, with back-off.
 template <bool WAIT, class Ready>
 __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, StateHeader *hdr, uint32_t lane,
-                                                 Ready ready) {
+                                                 uint32_t &spin_acc, Ready ready) {
   using gu64 = __attribute__((address_space(1))) const uint64_t;
   uint64_t v = 0;
   if constexpr (!WAIT) {
@@ -280,6 +302,7 @@ __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, Sta
         break;
       }
     }
+    spin_acc += spins;  // read by the diagnostic build only
     return v;
   }
 }
@@ -290,20 +313,20 @@ __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, Sta
 // predecessor has published; WAIT = false (two-pass): values are final.
 template <bool WAIT>
 __device__ __forceinline__ uint32_t prefix_before(const FrameState &fs, StateHeader *hdr, uint32_t lt,
-                                                  uint32_t lane) {
+                                                  uint32_t lane, uint32_t &spin_acc) {
   const uint32_t grp = lt / kGroupTiles;
   uint32_t sum = 0;
   for (uint32_t g0 = 0; g0 < grp; g0 += 64) {  // groups 0..grp-1 hold kGroupTiles tiles each
     const uint32_t gi = g0 + lane;
     const bool on = gi < grp;
-    const uint64_t v = read_counted<WAIT>(fs.group_acc + gi, on, hdr, lane,
+    const uint64_t v = read_counted<WAIT>(fs.group_acc + gi, on, hdr, lane, spin_acc,
                                           [](uint64_t x) { return uint32_t(x >> 32) == uint32_t(kGroupTiles); });
     sum += on ? uint32_t(v) : 0u;
   }
   {  // tiles grp*64 .. lt-1 of the own group (< 64 of them)
     const uint32_t ti = grp * kGroupTiles + lane;
     const bool on = ti < lt;
-    const uint64_t v = read_counted<WAIT>(fs.granules + ti, on, hdr, lane,
+    const uint64_t v = read_counted<WAIT>(fs.granules + ti, on, hdr, lane, spin_acc,
                                           [](uint64_t x) { return (x & kGranuleTag) != 0; });
     sum += on ? uint32_t(v) : 0u;
   }
@@ -313,12 +336,14 @@ __device__ __forceinline__ uint32_t prefix_before(const FrameState &fs, StateHea
 template <int DT, int QK, int PXT>
 __device__ __forceinline__ void tile_scatter(const TileRegs<DT, QK, PXT> &r, const uint64_t (&mask)[PXT],
                                              float4 *fout, uint32_t *fidx, uint32_t tile_prefix,
-                                             uint32_t cell_excl, uint32_t wave, uint32_t lane) {
+                                             uint32_t cell_excl, uint32_t wave, uint32_t lane, uint32_t roi_n) {
 #pragma unroll
   for (int k = 0; k < PXT; ++k) {
     const uint32_t cell = __builtin_amdgcn_readlane(cell_excl, k * (kBlock / 64) + int(wave));
     const uint32_t pos = tile_prefix + cell + mbcnt64(mask[k]);
-    if ((mask[k] >> lane) & 1) {
+    // pos < roi_n always holds for a correct prefix; the guard keeps a stale
+    // or timed-out prefix from ever becoming an out-of-bounds store
+    if (((mask[k] >> lane) & 1) && pos < roi_n) {
       store_point(fout, pos, r.X[k], r.Y[k], r.Z[k]);
       if (fidx) store_index(fidx, pos, r.pix[k]);
     }
@@ -338,13 +363,35 @@ __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restr
     const uint32_t f = fdiv(t, g.div_tpf);
     const uint32_t lt = t - f * g.tiles_per_frame;
     const uint32_t base = lt * uint32_t(kBlock * PXT);
-    TileRegs<DT, QK, PXT> r;
-    uint64_t mask[PXT];
-    tile_compute<DT, QK, PXT>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, base, tid);
-    tile_ballots<DT, QK, PXT>(r, g, base, tid, mask);
+    const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
     uint32_t c = 0;
+    if constexpr (QK == QK_STEREO) {
+      // predicate only: ~4 fp64 operations per pixel, the pass stays read-bound
+      float d[PXT];
+      uint32_t uu[PXT], vv[PXT];
+      Walker w(g, base + tid);
 #pragma unroll
-    for (int k = 0; k < PXT; ++k) c += uint32_t(__popcll(mask[k]));
+      for (int k = 0; k < PXT; ++k) {
+        uu[k] = w.u + g.border;
+        vv[k] = w.v + g.border;
+        const uint32_t off = vv[k] * g.row_stride + uu[k] * elem_bytes<DT>();
+        d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
+        w.step(g);
+      }
+#pragma unroll
+      for (int k = 0; k < PXT; ++k) {
+        const uint32_t i = base + uint32_t(k * kBlock) + tid;
+        const bool ok = (i < g.roi_n) && stereo_point_valid(Q, uu[k], vv[k], d[k], g.min_disparity);
+        c += uint32_t(__popcll(__ballot(ok)));
+      }
+    } else {
+      TileRegs<DT, QK, PXT> r;
+      uint64_t mask[PXT];
+      tile_compute<DT, QK, PXT>(r, fin, g, Q, base, tid);
+      tile_ballots<DT, QK, PXT>(r, g, base, tid, mask);
+#pragma unroll
+      for (int k = 0; k < PXT; ++k) c += uint32_t(__popcll(mask[k]));
+    }
     if (lane == 0) s_w[wave] = c;
     __syncthreads();
     if (tid == 0) {
@@ -352,11 +399,43 @@ __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restr
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) tot += s_w[w];
       const FrameState fs(state, g, f);
-      fs.granules[lt] = tot;
-      atomicAdd(reinterpret_cast<unsigned long long *>(fs.group_acc + lt / kGroupTiles), (unsigned long long)tot);
+      fs.granules[lt] = tot;  // plain store: the scan kernel reads it after the kernel boundary
     }
     __syncthreads();
   }
+}
+
+// K2a': per-frame exclusive scan of the tile counts, in place (one block per
+// frame; a 4K frame has ~2-8 thousand tiles, i.e. a few microseconds).
+__global__ __launch_bounds__(kBlock) void k_compact_scan(uint8_t *state, uint32_t *__restrict__ counts,
+                                                         const Geom g) {
+  __shared__ uint32_t s_w[kBlock / 64];
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+  const FrameState fs(state, g, blockIdx.x);
+  uint32_t carry = 0;
+  for (uint32_t b = 0; b < g.tiles_per_frame; b += kBlock) {
+    const uint32_t i = b + tid;
+    const uint32_t c = i < g.tiles_per_frame ? uint32_t(fs.granules[i]) : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t n = __shfl_up(incl, o, 64);
+      if (lane >= uint32_t(o)) incl += n;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+      const uint32_t x = s_w[w];
+      before += uint32_t(w) < wave ? x : 0u;
+      total += x;
+    }
+    if (i < g.tiles_per_frame) fs.granules[i] = carry + before + incl - c;
+    carry += total;
+    __syncthreads();
+  }
+  if (tid == 0) counts[blockIdx.x] = carry;
 }
 
 template <int DT, int QK, int PXT>
@@ -367,7 +446,6 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
                                                             const Geom g, const QArg<QK> Q) {
   constexpr int CELLS = PXT * (kBlock / 64);
   __shared__ uint32_t s_cnt[CELLS];
-  __shared__ uint32_t s_prefix;
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (uint32_t t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
     const uint32_t f = fdiv(t, g.div_tpf);
@@ -381,19 +459,14 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
 #pragma unroll
       for (int k = 0; k < PXT; ++k) s_cnt[k * (kBlock / 64) + wave] = uint32_t(__popcll(mask[k]));
     }
-    if (wave == 0) {
-      const FrameState fs(state, g, f);
-      const uint32_t p = prefix_before<false>(fs, nullptr, lt, lane);
-      if (lane == 0) s_prefix = p;
-    }
     __syncthreads();
     uint32_t total;
     const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
-    const uint32_t prefix = s_prefix;
+    const FrameState fs(state, g, f);
+    const uint32_t prefix = uint32_t(fs.granules[lt]);  // exclusive prefix left by k_compact_scan (uniform load)
     float4 *fout = out + uint64_t(f) * g.out_frame_stride;
     uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
-    tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane);
-    if (counts && lt == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + total;
+    tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane, g.roi_n);
     __syncthreads();
   }
 }
@@ -423,6 +496,10 @@ __global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__res
   __shared__ uint32_t s_ticket[2];
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
+  uint32_t spin_acc = 0;
+#ifdef D2PC_DIAG
+  unsigned long long dg[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
   for (uint32_t f = blockIdx.x % g.n_frames; f < g.n_frames; f += gridDim.x) {
     const FrameState fs(state, g, f);
@@ -435,10 +512,10 @@ __global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__res
     uint32_t lt = s_ticket[0];
     uint32_t it = 0;
     while (lt < g.tiles_per_frame) {
-      // take the NEXT ticket first: its round trip hides under this tile
-      uint32_t next_lt = 0;
-      if (tid == 0) next_lt = atomicAdd(fs.ticket, 1u);
-
+#ifdef D2PC_DIAG
+      const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+      unsigned long long c1 = 0, c2 = 0, c3 = 0;
+#endif
       const uint32_t base = lt * uint32_t(kBlock * PXT);
       TileRegs<DT, QK, PXT> r;
       uint64_t mask[PXT];
@@ -452,14 +529,29 @@ __global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__res
       uint32_t total;
       const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
       if (wave == 0) {
+        uint32_t next_lt = 0;
         if (lane == 0) {
           // publish: tagged granule (the data is the flag) + group accumulator
           __hip_atomic_store((gu64 *)(fs.granules + lt), kGranuleTag | total, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_fetch_add((gu64 *)(fs.group_acc + lt / kGroupTiles), (uint64_t(1) << 32) | total,
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // Take the next ticket only NOW, after publishing: a ticket held
+          // while its tile is not yet loading delays every later tile of the
+          // frame (they wait for its count), which locks the blocks in step.
+#ifdef D2PC_DIAG
+          c1 = __builtin_amdgcn_s_memtime();
+#endif
+          next_lt = atomicAdd(fs.ticket, 1u);
+#ifdef D2PC_DIAG
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          c2 = __builtin_amdgcn_s_memtime();
+#endif
         }
-        const uint32_t p = prefix_before<true>(fs, hdr, lt, lane);
+        const uint32_t p = prefix_before<true>(fs, hdr, lt, lane, spin_acc);
+#ifdef D2PC_DIAG
+        c3 = __builtin_amdgcn_s_memtime();
+#endif
         if (lane == 0) {
           s_prefix = p;
           s_ticket[(it + 1) & 1] = next_lt;
@@ -467,13 +559,26 @@ __global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__res
       }
       __syncthreads();
       const uint32_t prefix = s_prefix;
-      tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane);
+      tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane, g.roi_n);
       if (counts && lt == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + total;
+#ifdef D2PC_DIAG
+      if (tid == 0) {
+        const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+        dg[0] += 1; dg[1] += c1 - c0; dg[2] += c2 - c1; dg[3] += c3 - c2; dg[4] += c4 - c3; dg[5] += c4 - c0;
+      }
+#endif
       lt = s_ticket[(it + 1) & 1];
       ++it;
     }
     __syncthreads();
   }
+#ifdef D2PC_DIAG
+  if (tid == 0) {  // one flush per block
+    atomicAdd(&hdr->diag[0], dg[0]);
+    atomicAdd(&hdr->diag[1], (unsigned long long)spin_acc);
+    for (int j = 1; j < 6; ++j) atomicAdd(&hdr->diag[j + 1], dg[j]);
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------
@@ -507,14 +612,15 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
   const uint8_t *disp = static_cast<const uint8_t *>(a.disp);
   float4 *out = static_cast<float4 *>(a.out_points);
   uint8_t *state = static_cast<uint8_t *>(a.state);
-  hipError_t e = hipMemsetAsync(a.state, 0, a.state_bytes, a.stream);
-  if (e != hipSuccess) return e;
-  if (a.compact_algo == 1) {
+  if (a.compact_algo == 1) {  // count -> scan -> scatter: every state word is written before it is read
     hipLaunchKernelGGL((k_compact_count<DT, QK, PXT>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, state, a.geom,
                        make_qarg<QK>(a));
+    hipLaunchKernelGGL(k_compact_scan, dim3(a.geom.n_frames), dim3(kBlock), 0, a.stream, state, a.counts, a.geom);
     hipLaunchKernelGGL((k_compact_scatter<DT, QK, PXT>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, out,
                        a.out_index, a.counts, state, a.geom, make_qarg<QK>(a));
   } else {
+    hipError_t e = hipMemsetAsync(a.state, 0, a.state_bytes, a.stream);
+    if (e != hipSuccess) return e;
     // frame-static assignment: the grid is a multiple of n_frames, or smaller
     uint32_t grid = a.grid;
     if (grid >= a.geom.n_frames) grid -= grid % a.geom.n_frames;

@@ -67,8 +67,9 @@ typedef struct d2pc_config {
   int32_t border;         /* ROI inset on all four sides; cpp:70,72 => 40     */
   int32_t mode;           /* d2pc_mode                                        */
   float min_disparity;    /* COMPACT only: also drop d <= this; -inf = off    */
-  int32_t compact_algo;   /* 0 = library default; 1 = two-pass count/scatter;
-                             2 = single-pass counted hand-off                 */
+  int32_t compact_algo;   /* 0 = library default (two-pass); 1 = two-pass
+                             count/scatter; 2 = single-pass counted hand-off
+                             (experimental)                                   */
   int32_t reserved[4];
 } d2pc_config;
 

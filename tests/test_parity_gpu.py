@@ -249,6 +249,45 @@ def test_compact_edge_patterns(q_default, algo, pxt):
             assert_points_close(gp, wp, max_ulp=MAX_ULP, what=name)
 
 
+@pytest.mark.parametrize("algo", [1, 2])
+def test_compact_tiny_w_takes_exact_slow_path(algo):
+    """W so small that coordinates overflow float32 for part of the frame:
+    the count pass's cheap predicate must fall back to the real arithmetic
+    and agree with the scatter pass and the oracle point for point."""
+    q = d2pc.make_q()
+    q[14] = 1e-36  # W = 1e-36*d: between 'certainly finite' and zero
+    rng = np.random.default_rng(5)
+    disp = rng.uniform(1.0, 40.0, size=(300, 900)).astype(np.float32)
+    disp[rng.random(disp.shape) < 0.1] = 0.0
+    wp, wi = oracle.reproject_compact(disp, q, border=0)
+    assert 0.05 < len(wp) / disp.size < 0.95
+    with ctx_for(q, border=0, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+        gp, gi = ctx.process(disp, want_index=True)
+    assert np.array_equal(gi, wi)
+    assert_points_close(gp, wp, max_ulp=MAX_ULP)
+
+
+def test_general_and_stereo_kernels_agree_bitwise(q_default):
+    """The stereoRectify-structured specialisation drops only exact products:
+    it must reproduce the general kernel bit for bit, NaN/inf inputs included."""
+    disp = synth_disparity(3, 7, 700, 500, "holes")
+    disp[100, 100:110] = [np.nan, np.inf, -np.inf, -1.0, 1e-30, 3e38, 0.0, -0.0, 1e-45, 5.0]
+    with ctx_for(q_default) as ctx:
+        a = ctx.process(disp)
+        ctx.set_tuning("force_general_q", 1)
+        b = ctx.process(disp)
+        ctx.set_mode(d2pc.MODE_COMPACT)
+        cg, ig = ctx.process(disp, want_index=True)
+        ctx.set_tuning("force_general_q", 0)
+        cs, i_s = ctx.process(disp, want_index=True)
+    nan = np.isnan(a)
+    assert np.array_equal(nan, np.isnan(b)) and nan.sum() >= 9  # NaN payloads may differ, NaN-ness may not
+    assert np.array_equal(a.view(np.uint32)[~nan], b.view(np.uint32)[~nan])
+    assert np.array_equal(ig, i_s) and np.array_equal(cg.view(np.uint32), cs.view(np.uint32))
+    want = oracle.reproject(disp, q_default, border=40)
+    assert_points_close(a, want, max_ulp=MAX_ULP)
+
+
 def test_compact_min_disparity(q_default):
     disp = synth_disparity(3, 3, 400, 300, "holes")
     wp, wi = oracle.reproject_compact(disp, q_default, border=40, min_disparity=64.0)

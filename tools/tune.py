@@ -35,12 +35,17 @@ def main():
     ap.add_argument("--w", type=int, default=3840)
     ap.add_argument("--h", type=int, default=2160)
     ap.add_argument("--holes", type=float, default=0.0)
+    ap.add_argument("--modes", default="parity,compact")
+    ap.add_argument("--borders", default="40,0")
+    ap.add_argument("--algos", default="1,2")
     a = ap.parse_args()
     q = d2pc.make_q()
     g = torch.Generator(device="cuda").manual_seed(1)
     for mode, name in ((d2pc.MODE_PARITY, "parity"), (d2pc.MODE_COMPACT, "compact")):
-        for border in (40, 0):
-            for algo in ((0,) if mode == d2pc.MODE_PARITY else (1, 2)):
+        if name not in a.modes.split(","):
+            continue
+        for border in [int(x) for x in a.borders.split(",")]:
+            for algo in ((0,) if mode == d2pc.MODE_PARITY else [int(x) for x in a.algos.split(",")]):
                 for idx in (False, True) if mode == d2pc.MODE_COMPACT else (False,):
                     ctx = d2pc.Context(q=q, border=border, mode=mode, compact_algo=algo)
                     b = DeviceBatch(ctx, a.frames, a.h, a.w, want_index=idx)
