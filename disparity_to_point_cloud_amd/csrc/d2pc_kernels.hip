@@ -32,14 +32,17 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <int DT>
 __device__ __forceinline__ float load_disparity(const uint8_t *frame, uint32_t byte_off, float scale) {
   // `frame` is wave-uniform, `byte_off` a 32-bit per-lane offset: one
-  // global_load with an SGPR base.  Read once => nontemporal.
+  // global_load with an SGPR base.  Plain (cached) loads on purpose: with a
+  // border the 256-B wave segments are not line-aligned, so neighbouring
+  // waves share their edge lines; `nt` loads made L2 drop those lines and
+  // re-fetch them (measured: FETCH_SIZE 1.31x the algorithmic bytes).
   if constexpr (DT == DT_F32) {
-    return __builtin_nontemporal_load(reinterpret_cast<const float *>(frame + byte_off));
+    return *reinterpret_cast<const float *>(frame + byte_off);
   } else if constexpr (DT == DT_U8) {
     // cpp:61 convertTo(CV_32FC1, scale): product formed in fp32
-    return __fmul_rn(float(__builtin_nontemporal_load(frame + byte_off)), scale);
+    return __fmul_rn(float(*(frame + byte_off)), scale);
   } else {
-    return __fmul_rn(float(__builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(frame + byte_off))), scale);
+    return __fmul_rn(float(*reinterpret_cast<const uint16_t *>(frame + byte_off)), scale);
   }
 }
 

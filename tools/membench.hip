@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -36,6 +37,15 @@ template <bool NT, int PXT> __global__ void k_expand(const float *in, v4f *out, 
   }
 }
 
+// 4 B per lane reads (the d2pc kernels' load shape) of a known byte count:
+// calibrates rocprofv3's FETCH_SIZE for this access width on gfx950.
+__global__ void k_read4(const float *in, float *sink, size_t n) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x, st = size_t(gridDim.x) * blockDim.x;
+  float acc = 0;
+  for (; i < n; i += st) acc += __builtin_nontemporal_load(in + i);
+  if (acc == 123.456f) *sink = acc;
+}
+
 template <class F> double time_ms(F f, int iters) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   f(); f(); CK(hipDeviceSynchronize());
@@ -56,6 +66,16 @@ int main(int argc, char **argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device %s, %d CUs\n", prop.gcnArchName, prop.multiProcessorCount);
   const int cus = prop.multiProcessorCount;
+  if (argc > 1 && !strcmp(argv[1], "calib")) {
+    // known traffic for PMC calibration: read n*4 bytes with dword loads, 3 launches;
+    // then read n*16 bytes with dwordx4 loads, 3 launches; then write n*16 bytes, 3 launches
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_read4, dim3(cus * 8), dim3(256), 0, 0, in, sink, n * 4);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_read<false>, dim3(cus * 8), dim3(256), 0, 0, (const v4f *)in, sink, n);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_fill<false>, dim3(cus * 8), dim3(256), 0, 0, out, n);
+    CK(hipDeviceSynchronize());
+    printf("calib: k_read4 reads %zu bytes; k_read reads %zu bytes; k_fill writes %zu bytes per launch\n", n * 16, n * 16, n * 16);
+    return 0;
+  }
   for (int bpc : {4, 8, 16, 32}) {
     const int grid = cus * bpc;
     double ms;
