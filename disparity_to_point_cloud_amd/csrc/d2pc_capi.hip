@@ -30,6 +30,7 @@ struct d2pc_ctx {
   int pxt_parity = 16, pxt_compact = 16;
   int blocks_per_cu = 16;
   int force_general_q = 0;
+  int no_vec_rows = 0;
   // device scratch
   void *d_state = nullptr;   size_t state_cap = 0;
   void *d_in = nullptr;      size_t in_cap = 0;
@@ -126,8 +127,12 @@ int make_geom(d2pc_ctx *ctx, int dtype, float scale, int width, int height, size
   g->groups_per_frame = (g->tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
   g->frame_state_stride = frame_state_stride(g->tiles_per_frame);
   const uint32_t rw = g->roi_w ? g->roi_w : 1u;
-  g->step_v = uint32_t(kBlock) / rw;
-  g->step_u = uint32_t(kBlock) % rw;
+  g->s64_v = 64u / rw;
+  g->s64_u = 64u % rw;
+  g->s832_v = 832u / rw;
+  g->s832_u = 832u % rw;
+  g->s1024_v = 1024u / rw;
+  g->s1024_u = 1024u % rw;
   g->div_roi_w = make_fastdiv(rw);
   g->div_tpf = make_fastdiv(g->tiles_per_frame ? g->tiles_per_frame : 1u);
   g->row_stride = uint32_t(row_stride);
@@ -152,6 +157,10 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   memcpy(a.q.q, ctx->q, sizeof a.q.q);
   a.qs = ctx->qs;
   a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
+  // 16-B row loads need every aligned group of four ROI pixels to sit in one
+  // row at a 16-B aligned address
+  a.vec_rows = !ctx->no_vec_rows && dtype == D2PC_DTYPE_F32 && g.roi_w % 4 == 0 && g.border % 4 == 0 &&
+               g.row_stride % 16 == 0 && g.in_frame_stride % 16 == 0 && reinterpret_cast<uintptr_t>(d_disp) % 16 == 0;
   {
     // bound on |u + cx|, |v + cy|, |f| over the frame, scaled by 2^-126: any
     // |W| at least this large keeps every quotient below 2^126 < FLT_MAX
@@ -412,6 +421,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 64) ctx->blocks_per_cu = value;
   else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
+  else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
   return D2PC_OK;
 }

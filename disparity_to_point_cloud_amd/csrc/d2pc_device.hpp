@@ -46,7 +46,9 @@ struct Geom {
   uint32_t groups_per_frame;          // compaction: ceil(tiles_per_frame/64)
   uint32_t row_stride;                // bytes between image rows (< 2^32)
   uint32_t last_off;                  // byte offset of the frame's last ROI pixel
-  uint32_t step_v, step_u;            // kBlock = step_v*roi_w + step_u
+  uint32_t s64_v, s64_u;              // 64   = s64_v*roi_w + s64_u   (next slot)
+  uint32_t s832_v, s832_u;            // 832  pixels: slot 3 -> slot 0 of the next batch
+  uint32_t s1024_v, s1024_u;          // 1024 pixels: one batch (16-B row loads)
   uint32_t frame_state_stride;        // compaction: bytes of state per frame
   FastDiv div_roi_w, div_tpf;
   uint64_t in_frame_stride;           // bytes between frames

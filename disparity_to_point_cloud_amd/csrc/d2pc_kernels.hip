@@ -26,6 +26,37 @@ namespace d2pc {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Cache-policy knobs.  tools/ab.py builds the library with other values and
+// times all builds interleaved in ONE process on ONE set of buffers (timings
+// differ by +-6 % between allocations and ~10 % between devices, so nothing
+// else ranks variants).  Measured on MI355X, 16 x 4K frames per launch:
+//   loads : plain beats nt by 1-2 % (with a border the 256-B / 1-KiB wave
+//           pieces are not line-aligned; nt makes L2 drop the shared edge
+//           lines and re-fetch them: FETCH_SIZE 1.31x vs 1.07x algorithmic)
+//   stores: nt beats plain by ~2 % (points are written once, never re-read)
+#ifndef D2PC_LOAD_NT
+#define D2PC_LOAD_NT 0
+#endif
+#ifndef D2PC_STORE_NT
+#define D2PC_STORE_NT 1
+#endif
+template <class T>
+__device__ __forceinline__ T ld(const T *p) {
+#if D2PC_LOAD_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void st(T *p, T v) {
+#if D2PC_STORE_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // --------------------------------------------------------------------------
 // per-pixel pieces
 // --------------------------------------------------------------------------
@@ -37,12 +68,12 @@ __device__ __forceinline__ float load_disparity(const uint8_t *frame, uint32_t b
   // waves share their edge lines; `nt` loads made L2 drop those lines and
   // re-fetch them (measured: FETCH_SIZE 1.31x the algorithmic bytes).
   if constexpr (DT == DT_F32) {
-    return *reinterpret_cast<const float *>(frame + byte_off);
+    return ld(reinterpret_cast<const float *>(frame + byte_off));
   } else if constexpr (DT == DT_U8) {
     // cpp:61 convertTo(CV_32FC1, scale): product formed in fp32
-    return __fmul_rn(float(*(frame + byte_off)), scale);
+    return __fmul_rn(float(ld(frame + byte_off)), scale);
   } else {
-    return __fmul_rn(float(*reinterpret_cast<const uint16_t *>(frame + byte_off)), scale);
+    return __fmul_rn(float(ld(reinterpret_cast<const uint16_t *>(frame + byte_off))), scale);
   }
 }
 
@@ -103,11 +134,11 @@ __device__ __forceinline__ void store_point(float4 *frame_out, uint32_t point, f
   // pcl::PointXYZ = {x,y,z,1.0f} (cpp:74): one global_store_dwordx4 with an
   // SGPR base and a 32-bit byte offset (host guarantees roi_n <= 2^28).
   const v4f p = {X, Y, Z, 1.0f};
-  *reinterpret_cast<v4f *>(reinterpret_cast<uint8_t *>(frame_out) + (point << 4)) = p;
+  st(reinterpret_cast<v4f *>(reinterpret_cast<uint8_t *>(frame_out) + (point << 4)), p);
 }
 
 __device__ __forceinline__ void store_index(uint32_t *frame_idx, uint32_t point, uint32_t pix) {
-  *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(frame_idx) + (point << 2)) = pix;
+  st(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(frame_idx) + (point << 2)), pix);
 }
 
 // Exact validity of a STEREO-structured point WITHOUT evaluating it (used by
@@ -132,17 +163,30 @@ __device__ __forceinline__ bool stereo_point_valid(const QArg<QK_STEREO> &A, uin
   return ok && !(d <= min_disparity);
 }
 
-// ROI coordinates of the thread's pixel in slot 0 of a tile, then stepped by
-// kBlock pixels per slot: kBlock = step_v*roi_w + step_u.
+// ---- pixel <-> (slot, wave, lane) mapping of a tile -------------------------
+// A tile is 256*PXT consecutive ROI pixels, cut into batches of 1024; inside a
+// batch each WAVE owns 256 consecutive pixels and walks them in 4 slots of 64:
+//   pixel(k, wave, lane) = base + (k/4)*1024 + wave*256 + (k%4)*64 + lane
+// so a wave's store for slot k is one contiguous 1-KiB piece, and a wave's
+// input for a batch is one contiguous 1-KiB piece as well (staged through a
+// wave-private LDS strip when it can be fetched 16 B per lane).
+__device__ __forceinline__ uint32_t slot_pixel(uint32_t base, uint32_t wave, uint32_t lane, int k) {
+  return base + uint32_t(k >> 2) * 1024u + wave * 256u + uint32_t(k & 3) * 64u + lane;
+}
+// Row-major order of the (slot, wave) cells == pixel order inside the tile.
+__device__ __forceinline__ int cell_index(int k, uint32_t wave) { return ((k >> 2) * 4 + int(wave)) * 4 + (k & 3); }
+
+// ROI coordinates of a pixel, advanced by constant pixel counts whose
+// (rows, columns) decomposition the host precomputed.
 struct Walker {
   uint32_t u, v;  // ROI-relative column / row
   __device__ __forceinline__ Walker(const Geom &g, uint32_t i0) {
     v = fdiv(i0, g.div_roi_w);
     u = i0 - v * g.roi_w;
   }
-  __device__ __forceinline__ void step(const Geom &g) {
-    u += g.step_u;
-    v += g.step_v;
+  __device__ __forceinline__ void step(const Geom &g, uint32_t dv, uint32_t du) {
+    u += du;
+    v += dv;
     if (u >= g.roi_w) {
       u -= g.roi_w;
       ++v;
@@ -150,47 +194,100 @@ struct Walker {
   }
 };
 
-// Loads + reprojects the PXT pixels of one thread.  Loads are issued first
-// (PXT independent dword loads in flight), arithmetic second.
+// Disparities + image coordinates of the PXT pixels of one thread.
+template <int PXT>
+struct TileIn {
+  float d[PXT];
+  uint32_t uu[PXT], vv[PXT];  // image coordinates (border added)
+};
+
+// Loads are issued first (all in flight), arithmetic comes later.
+//  VEC = false: one dword per lane and slot (any dtype, any alignment).
+//  VEC = true : fp32 rows whose 4-pixel groups are 16-B aligned and never
+//               straddle a ROI row (host-checked): one 16-B load per lane and
+//               batch (a 1-KiB coalesced piece per wave), transposed to the
+//               slot layout through the wave's own LDS strip.  LDS is in-order
+//               per wave, so no barrier is involved.
+template <int DT, int PXT, bool VEC>
+__device__ __forceinline__ void tile_load(TileIn<PXT> &t, const uint8_t *fin, const Geom &g, uint32_t base,
+                                          uint32_t wave, uint32_t lane, float *wave_strip) {
+  Walker w(g, base + wave * 256u + lane);
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    t.uu[k] = w.u + g.border;
+    t.vv[k] = w.v + g.border;
+    if ((k & 3) == 3) w.step(g, g.s832_v, g.s832_u);  // to slot 0 of the next batch
+    else w.step(g, g.s64_v, g.s64_u);
+  }
+  if constexpr (!VEC) {
+#pragma unroll
+    for (int k = 0; k < PXT; ++k) {
+      // byte offsets grow with the ROI index, so clamping to the last ROI
+      // pixel keeps the tail slots of a frame's last tile in bounds without
+      // predicating the loads (their results are never stored)
+      const uint32_t off = t.vv[k] * g.row_stride + t.uu[k] * elem_bytes<DT>();
+      t.d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
+    }
+  } else {
+    static_assert(!VEC || DT == DT_F32, "16-B row loads are fp32 only");
+    v4f q[PXT / 4];
+    Walker w4(g, base + wave * 256u + lane * 4u);
+#pragma unroll
+    for (int j = 0; j < PXT / 4; ++j) {
+      const uint32_t off = (w4.v + g.border) * g.row_stride + (w4.u + g.border) * 4u;
+      const uint32_t last4 = g.last_off - 12u;  // the frame's last aligned group
+      q[j] = ld(reinterpret_cast<const v4f *>(fin + (off < last4 ? off : last4)));
+      w4.step(g, g.s1024_v, g.s1024_u);
+    }
+#pragma unroll
+    for (int j = 0; j < PXT / 4; ++j) {
+      *reinterpret_cast<v4f *>(wave_strip + lane * 4u) = q[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) t.d[j * 4 + sl] = wave_strip[uint32_t(sl) * 64u + lane];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 template <int DT, int QK, int PXT>
 struct TileRegs {
   float X[PXT], Y[PXT], Z[PXT], d[PXT];
   uint32_t pix[PXT];  // source pixel index v*W+u (image coordinates)
 };
 
-template <int DT, int QK, int PXT>
+template <int DT, int QK, int PXT, bool VEC>
 __device__ __forceinline__ void tile_compute(TileRegs<DT, QK, PXT> &r, const uint8_t *fin, const Geom &g,
-                                             const QArg<QK> &Q, uint32_t base, uint32_t tid) {
-  uint32_t uu[PXT], vv[PXT];
-  Walker w(g, base + tid);
+                                             const QArg<QK> &Q, uint32_t base, uint32_t wave, uint32_t lane,
+                                             float *wave_strip) {
+  TileIn<PXT> t;
+  tile_load<DT, PXT, VEC>(t, fin, g, base, wave, lane, wave_strip);
 #pragma unroll
   for (int k = 0; k < PXT; ++k) {
-    uu[k] = w.u + g.border;
-    vv[k] = w.v + g.border;
-    // byte offsets grow with the ROI index, so clamping to the last ROI
-    // pixel keeps the tail slots of a frame's last tile in bounds without
-    // predicating the loads (their results are never stored)
-    const uint32_t off = vv[k] * g.row_stride + uu[k] * elem_bytes<DT>();
-    r.d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
-    w.step(g);
-  }
-#pragma unroll
-  for (int k = 0; k < PXT; ++k) {
-    reproject(Q, uu[k], vv[k], r.d[k], r.X[k], r.Y[k], r.Z[k]);
-    r.pix[k] = vv[k] * g.width + uu[k];
+    r.d[k] = t.d[k];
+    reproject(Q, t.uu[k], t.vv[k], t.d[k], r.X[k], r.Y[k], r.Z[k]);
+    r.pix[k] = t.vv[k] * g.width + t.uu[k];
   }
 }
+
+// Wave-private staging strips for the VEC load path (1 KiB per wave).
+#define D2PC_DECLARE_STRIPS(VEC, wave)                                  \
+  __shared__ float s_strips_[(VEC) ? (kBlock / 64) * 256 : 1];         \
+  float *wave_strip = (VEC) ? s_strips_ + (wave) * 256u : nullptr
 
 // --------------------------------------------------------------------------
 // K1: PARITY mode -- every ROI pixel, reference order, nothing filtered.
 // --------------------------------------------------------------------------
-template <int DT, int QK, int PXT>
+template <int DT, int QK, int PXT, bool VEC>
 __global__ __launch_bounds__(kBlock) void k_reproject_pack(const uint8_t *__restrict__ disp,
                                                            float4 *__restrict__ out,
                                                            uint32_t *__restrict__ out_index,
                                                            uint32_t *__restrict__ counts, const Geom g,
                                                            const QArg<QK> Q) {
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  D2PC_DECLARE_STRIPS(VEC, wave);
   for (uint32_t t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
     const uint32_t f = fdiv(t, g.div_tpf);
     const uint32_t lt = t - f * g.tiles_per_frame;
@@ -199,10 +296,10 @@ __global__ __launch_bounds__(kBlock) void k_reproject_pack(const uint8_t *__rest
     uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
     const uint32_t base = lt * uint32_t(kBlock * PXT);
     TileRegs<DT, QK, PXT> r;
-    tile_compute<DT, QK, PXT>(r, fin, g, Q, base, tid);
+    tile_compute<DT, QK, PXT, VEC>(r, fin, g, Q, base, wave, lane, wave_strip);
 #pragma unroll
     for (int k = 0; k < PXT; ++k) {
-      const uint32_t i = base + uint32_t(k * kBlock) + tid;
+      const uint32_t i = slot_pixel(base, wave, lane, k);
       if (i < g.roi_n) {
         store_point(fout, i, r.X[k], r.Y[k], r.Z[k]);
         if (fidx) store_index(fidx, i, r.pix[k]);
@@ -231,10 +328,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
 // Validity ballots of a computed tile, one 64-bit wave mask per slot.
 template <int DT, int QK, int PXT>
 __device__ __forceinline__ void tile_ballots(const TileRegs<DT, QK, PXT> &r, const Geom &g, uint32_t base,
-                                             uint32_t tid, uint64_t (&mask)[PXT]) {
+                                             uint32_t wave, uint32_t lane, uint64_t (&mask)[PXT]) {
 #pragma unroll
   for (int k = 0; k < PXT; ++k) {
-    const uint32_t i = base + uint32_t(k * kBlock) + tid;
+    const uint32_t i = slot_pixel(base, wave, lane, k);
     const bool ok = (i < g.roi_n) && point_is_valid(r.X[k], r.Y[k], r.Z[k], r.d[k], g.min_disparity);
     mask[k] = __ballot(ok);
   }
@@ -242,7 +339,7 @@ __device__ __forceinline__ void tile_ballots(const TileRegs<DT, QK, PXT> &r, con
 
 // Exclusive offsets of every (slot, wave) cell of a block in row-major
 // (slot-major, wave-minor) order == pixel order inside the tile.
-// s_cnt[k*4 + w] holds the wave's popcount for slot k.  Returns the
+// s_cnt[cell_index(k, w)] holds wave w's popcount for slot k.  Returns the
 // exclusive scan in lanes 0..CELLS-1 and the tile total in `total`.
 template <int CELLS>
 __device__ __forceinline__ uint32_t scan_cells(const uint32_t *s_cnt, uint32_t lane, uint32_t &total) {
@@ -342,7 +439,7 @@ __device__ __forceinline__ void tile_scatter(const TileRegs<DT, QK, PXT> &r, con
                                              uint32_t cell_excl, uint32_t wave, uint32_t lane, uint32_t roi_n) {
 #pragma unroll
   for (int k = 0; k < PXT; ++k) {
-    const uint32_t cell = __builtin_amdgcn_readlane(cell_excl, k * (kBlock / 64) + int(wave));
+    const uint32_t cell = __builtin_amdgcn_readlane(cell_excl, cell_index(k, wave));
     const uint32_t pos = tile_prefix + cell + mbcnt64(mask[k]);
     // pos < roi_n always holds for a correct prefix; the guard keeps a stale
     // or timed-out prefix from ever becoming an out-of-bounds store
@@ -356,12 +453,13 @@ __device__ __forceinline__ void tile_scatter(const TileRegs<DT, QK, PXT> &r, con
 // --------------------------------------------------------------------------
 // K2a/K2b: two-pass compaction (count -> scatter).  No in-launch hand-off.
 // --------------------------------------------------------------------------
-template <int DT, int QK, int PXT>
+template <int DT, int QK, int PXT, bool VEC>
 __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restrict__ disp, uint8_t *state,
                                                           const Geom g, const QArg<QK> Q) {
   constexpr int WAVES = kBlock / 64;
   __shared__ uint32_t s_w[WAVES];
-  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  D2PC_DECLARE_STRIPS(VEC, wave);
   for (uint32_t t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
     const uint32_t f = fdiv(t, g.div_tpf);
     const uint32_t lt = t - f * g.tiles_per_frame;
@@ -370,28 +468,19 @@ __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restr
     uint32_t c = 0;
     if constexpr (QK == QK_STEREO) {
       // predicate only: ~4 fp64 operations per pixel, the pass stays read-bound
-      float d[PXT];
-      uint32_t uu[PXT], vv[PXT];
-      Walker w(g, base + tid);
+      TileIn<PXT> in;
+      tile_load<DT, PXT, VEC>(in, fin, g, base, wave, lane, wave_strip);
 #pragma unroll
       for (int k = 0; k < PXT; ++k) {
-        uu[k] = w.u + g.border;
-        vv[k] = w.v + g.border;
-        const uint32_t off = vv[k] * g.row_stride + uu[k] * elem_bytes<DT>();
-        d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
-        w.step(g);
-      }
-#pragma unroll
-      for (int k = 0; k < PXT; ++k) {
-        const uint32_t i = base + uint32_t(k * kBlock) + tid;
-        const bool ok = (i < g.roi_n) && stereo_point_valid(Q, uu[k], vv[k], d[k], g.min_disparity);
+        const uint32_t i = slot_pixel(base, wave, lane, k);
+        const bool ok = (i < g.roi_n) && stereo_point_valid(Q, in.uu[k], in.vv[k], in.d[k], g.min_disparity);
         c += uint32_t(__popcll(__ballot(ok)));
       }
     } else {
       TileRegs<DT, QK, PXT> r;
       uint64_t mask[PXT];
-      tile_compute<DT, QK, PXT>(r, fin, g, Q, base, tid);
-      tile_ballots<DT, QK, PXT>(r, g, base, tid, mask);
+      tile_compute<DT, QK, PXT, VEC>(r, fin, g, Q, base, wave, lane, wave_strip);
+      tile_ballots<DT, QK, PXT>(r, g, base, wave, lane, mask);
 #pragma unroll
       for (int k = 0; k < PXT; ++k) c += uint32_t(__popcll(mask[k]));
     }
@@ -441,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_scan(uint8_t *state, uint32_
   if (tid == 0) counts[blockIdx.x] = carry;
 }
 
-template <int DT, int QK, int PXT>
+template <int DT, int QK, int PXT, bool VEC>
 __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__restrict__ disp,
                                                             float4 *__restrict__ out,
                                                             uint32_t *__restrict__ out_index,
@@ -449,18 +538,19 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
                                                             const Geom g, const QArg<QK> Q) {
   constexpr int CELLS = PXT * (kBlock / 64);
   __shared__ uint32_t s_cnt[CELLS];
-  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  D2PC_DECLARE_STRIPS(VEC, wave);
   for (uint32_t t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
     const uint32_t f = fdiv(t, g.div_tpf);
     const uint32_t lt = t - f * g.tiles_per_frame;
     const uint32_t base = lt * uint32_t(kBlock * PXT);
     TileRegs<DT, QK, PXT> r;
     uint64_t mask[PXT];
-    tile_compute<DT, QK, PXT>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, base, tid);
-    tile_ballots<DT, QK, PXT>(r, g, base, tid, mask);
+    tile_compute<DT, QK, PXT, VEC>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, base, wave, lane, wave_strip);
+    tile_ballots<DT, QK, PXT>(r, g, base, wave, lane, mask);
     if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < PXT; ++k) s_cnt[k * (kBlock / 64) + wave] = uint32_t(__popcll(mask[k]));
+      for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = uint32_t(__popcll(mask[k]));
     }
     __syncthreads();
     uint32_t total;
@@ -486,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
 //    before publishing), so there is no serial chain: the wait is for the
 //    slowest predecessor's load, not for a scan to ripple through.
 // --------------------------------------------------------------------------
-template <int DT, int QK, int PXT>
+template <int DT, int QK, int PXT, bool VEC>
 __global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__restrict__ disp,
                                                             float4 *__restrict__ out,
                                                             uint32_t *__restrict__ out_index,
@@ -497,7 +587,8 @@ __global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__res
   __shared__ uint32_t s_cnt[CELLS];
   __shared__ uint32_t s_prefix;
   __shared__ uint32_t s_ticket[2];
-  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  D2PC_DECLARE_STRIPS(VEC, wave);
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
   uint32_t spin_acc = 0;
 #ifdef D2PC_DIAG
@@ -522,11 +613,11 @@ __global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__res
       const uint32_t base = lt * uint32_t(kBlock * PXT);
       TileRegs<DT, QK, PXT> r;
       uint64_t mask[PXT];
-      tile_compute<DT, QK, PXT>(r, fin, g, Q, base, tid);
-      tile_ballots<DT, QK, PXT>(r, g, base, tid, mask);
+      tile_compute<DT, QK, PXT, VEC>(r, fin, g, Q, base, wave, lane, wave_strip);
+      tile_ballots<DT, QK, PXT>(r, g, base, wave, lane, mask);
       if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < PXT; ++k) s_cnt[k * (kBlock / 64) + wave] = uint32_t(__popcll(mask[k]));
+        for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = uint32_t(__popcll(mask[k]));
       }
       __syncthreads();
       uint32_t total;
@@ -602,24 +693,24 @@ QArg<QK_STEREO> make_qarg<QK_STEREO>(const LaunchArgs &a) {
   return r;
 }
 
-template <int DT, int QK, int PXT>
+template <int DT, int QK, int PXT, bool VEC>
 static hipError_t launch_parity_t(const LaunchArgs &a) {
-  hipLaunchKernelGGL((k_reproject_pack<DT, QK, PXT>), dim3(a.grid), dim3(kBlock), 0, a.stream,
+  hipLaunchKernelGGL((k_reproject_pack<DT, QK, PXT, VEC>), dim3(a.grid), dim3(kBlock), 0, a.stream,
                      static_cast<const uint8_t *>(a.disp), static_cast<float4 *>(a.out_points), a.out_index,
                      a.counts, a.geom, make_qarg<QK>(a));
   return hipGetLastError();
 }
 
-template <int DT, int QK, int PXT>
+template <int DT, int QK, int PXT, bool VEC>
 static hipError_t launch_compact_t(const LaunchArgs &a) {
   const uint8_t *disp = static_cast<const uint8_t *>(a.disp);
   float4 *out = static_cast<float4 *>(a.out_points);
   uint8_t *state = static_cast<uint8_t *>(a.state);
   if (a.compact_algo == 1) {  // count -> scan -> scatter: every state word is written before it is read
-    hipLaunchKernelGGL((k_compact_count<DT, QK, PXT>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, state, a.geom,
+    hipLaunchKernelGGL((k_compact_count<DT, QK, PXT, VEC>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, state, a.geom,
                        make_qarg<QK>(a));
     hipLaunchKernelGGL(k_compact_scan, dim3(a.geom.n_frames), dim3(kBlock), 0, a.stream, state, a.counts, a.geom);
-    hipLaunchKernelGGL((k_compact_scatter<DT, QK, PXT>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, out,
+    hipLaunchKernelGGL((k_compact_scatter<DT, QK, PXT, VEC>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, out,
                        a.out_index, a.counts, state, a.geom, make_qarg<QK>(a));
   } else {
     hipError_t e = hipMemsetAsync(a.state, 0, a.state_bytes, a.stream);
@@ -627,7 +718,7 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
     // frame-static assignment: the grid is a multiple of n_frames, or smaller
     uint32_t grid = a.grid;
     if (grid >= a.geom.n_frames) grid -= grid % a.geom.n_frames;
-    hipLaunchKernelGGL((k_compact_onepass<DT, QK, PXT>), dim3(grid), dim3(kBlock), 0, a.stream, disp, out,
+    hipLaunchKernelGGL((k_compact_onepass<DT, QK, PXT, VEC>), dim3(grid), dim3(kBlock), 0, a.stream, disp, out,
                        a.out_index, a.counts, state, a.geom, make_qarg<QK>(a));
   }
   return hipGetLastError();
@@ -636,9 +727,11 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
 template <int QK, int PXT>
 static hipError_t dispatch_dtype(const LaunchArgs &a, bool compact) {
   switch (a.dtype) {
-    case DT_F32: return compact ? launch_compact_t<DT_F32, QK, PXT>(a) : launch_parity_t<DT_F32, QK, PXT>(a);
-    case DT_U8: return compact ? launch_compact_t<DT_U8, QK, PXT>(a) : launch_parity_t<DT_U8, QK, PXT>(a);
-    case DT_U16: return compact ? launch_compact_t<DT_U16, QK, PXT>(a) : launch_parity_t<DT_U16, QK, PXT>(a);
+    case DT_F32:
+      if (a.vec_rows) return compact ? launch_compact_t<DT_F32, QK, PXT, true>(a) : launch_parity_t<DT_F32, QK, PXT, true>(a);
+      return compact ? launch_compact_t<DT_F32, QK, PXT, false>(a) : launch_parity_t<DT_F32, QK, PXT, false>(a);
+    case DT_U8: return compact ? launch_compact_t<DT_U8, QK, PXT, false>(a) : launch_parity_t<DT_U8, QK, PXT, false>(a);
+    case DT_U16: return compact ? launch_compact_t<DT_U16, QK, PXT, false>(a) : launch_parity_t<DT_U16, QK, PXT, false>(a);
   }
   return hipErrorInvalidValue;
 }

@@ -19,7 +19,8 @@ struct LaunchArgs {
   size_t state_bytes = 0;
   int dtype = DT_F32;
   int pxt = 4;                    // ROI pixels per thread (tile = 256*pxt)
-  int compact_algo = 2;           // 1 two-pass, 2 single-pass
+  int compact_algo = 1;           // 1 two-pass, 2 single-pass
+  bool vec_rows = false;          // fp32 rows fetchable 16 B per lane (alignment checked by the host)
   uint32_t grid = 1;
   hipStream_t stream = nullptr;
   Geom geom{};

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of library builds and launch shapes in ONE process
+on ONE device (devices and runs differ by ~10 %, so only this kind of
+comparison ranks variants).  GPU box only.
+
+  python tools/ab.py --libs base,ntload,ntstore --modes parity --borders 40,0
+"""
+import argparse, ctypes, itertools, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from disparity_to_point_cloud_amd import capi
+
+def load_variant(name):
+    capi._lib = None
+    capi._LIB_NAME = "libd2pc.so" if name == "base" else f"libd2pc_{name}.so"
+    return capi.load_library()
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--libs", default="base")
+    ap.add_argument("--modes", default="parity")
+    ap.add_argument("--borders", default="40")
+    ap.add_argument("--pxts", default="16")
+    ap.add_argument("--bpcs", default="16")
+    ap.add_argument("--novecs", default="0")
+    ap.add_argument("--algos", default="1")
+    ap.add_argument("--idx", type=int, default=0)
+    ap.add_argument("--holes", type=float, default=0.0)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=16)
+    a = ap.parse_args()
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    import disparity_to_point_cloud_amd as d2pc
+    g = torch.Generator(device="cuda").manual_seed(1)
+    disp = torch.rand((a.frames, 2160, 3840), generator=g, device="cuda") * 127.5 + 0.5
+    if a.holes > 0:
+        disp.mul_((torch.rand(disp.shape, generator=g, device="cuda") >= a.holes).float())
+    cands = []
+    # ONE set of buffers for every candidate: kernel time depends on which
+    # physical pages a buffer got (+-6 % between allocations of one process)
+    W, H, F = 3840, 2160, a.frames
+    stride = (W * H + 15) // 16 * 16
+    points = torch.empty((F, stride, 4), dtype=torch.float32, device="cuda")
+    index = torch.empty((F, stride), dtype=torch.int32, device="cuda") if a.idx else None
+    counts = torch.zeros((F,), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    class Cand:
+        def __init__(self, ctx):
+            self.ctx = ctx
+            ctx.reserve(W, H, F)
+        def launch(self):
+            self.ctx.process_device(disp.data_ptr(), 0, 1.0, W, H, W * 4, W * H * 4, F, points.data_ptr(),
+                                    index.data_ptr() if index is not None else None, stride, counts.data_ptr(), stream)
+
+    for lib in a.libs.split(","):
+        L = load_variant(lib)
+        for mode, border, pxt, bpc, nv, algo in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(",")):
+            m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
+            ctx = capi.Context(q=capi.make_q(), border=int(border), mode=m, compact_algo=int(algo))
+            ctx.set_tuning("pxt_parity", int(pxt)); ctx.set_tuning("pxt_compact", int(pxt))
+            ctx.set_tuning("blocks_per_cu", int(bpc)); ctx.set_tuning("no_vec_rows", int(nv))
+            b = Cand(ctx)
+            b.launch(); torch.cuda.synchronize()
+            npts = int(counts.sum().item())
+            roi_n = capi.roi_points(W, H, int(border))
+            alg = 4 * F * roi_n + (20 if a.idx else 16) * npts
+            cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo}", b, alg, []))
+    for r in range(a.rounds):
+        for label, b, alg, ts in cands:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                b.launch()
+            e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1) / a.iters)
+    for label, b, alg, ts in cands:
+        ts = np.array(ts[1:]) * 1e3
+        print(f"{label}: med {np.median(ts):7.1f} us  min {ts.min():7.1f}  max {ts.max():7.1f}   {alg/np.median(ts)/1e3:7.1f} GB/s", flush=True)
+
+if __name__ == "__main__":
+    main()

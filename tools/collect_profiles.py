@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of one round (gpurun_out/prof_rNN_*) into the
+tracked files under profiles/:
+  rNN_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary (verbatim)
+  rNN_pmc_summary.json      FETCH_SIZE / WRITE_SIZE per kernel (+ calibration)
+  hbm_traffic.json          HBM bytes per launch, read by bench.py ("traffic")
+Corrections follow MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are
+in KiB; on gfx950 FETCH_SIZE tallies a 128-B request as 64 B, so it is doubled
+-- confirmed here for THIS kernel's load shape by the calibration pass
+(tools/membench calib: known byte counts read with dword and dwordx4 loads).
+"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+num = rnd[1:].lstrip("0") or "0"
+tag = f"prof_r{num}"
+
+def one(pattern):
+    fs = sorted(glob.glob(os.path.join(src, pattern)))
+    return fs[-1] if fs else None
+
+stats = one(f"{tag}_stats/*/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+
+def counters(dirname):
+    out = collections.defaultdict(list)
+    f = one(f"{dirname}/*/*_counter_collection.csv")
+    if not f:
+        return out
+    for r in csv.DictReader(open(f)):
+        out[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return out
+
+summary = {"units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; *_bytes corrected", "kernels": {}, "calibration": {}}
+cal_f, cal_w = counters(f"{tag}_calib_fetch"), counters(f"{tag}_calib_write")
+known = 16 * 3840 * 2160 * 16  # bytes per membench calib launch
+fetch_factor = None
+for (k, c), v in cal_f.items():
+    if k.endswith("k_read4") and c == "FETCH_SIZE":
+        fetch_factor = known / (sum(v) / len(v) * 1024)
+        summary["calibration"]["k_read4 (dword loads, known %d B)" % known] = {"FETCH_SIZE_KiB": sum(v) / len(v), "true/reported": fetch_factor}
+    if "k_read<" in k and c == "FETCH_SIZE":
+        summary["calibration"]["k_read (dwordx4 loads, known %d B)" % known] = {"FETCH_SIZE_KiB": sum(v) / len(v), "true/reported": known / (sum(v) / len(v) * 1024)}
+for (k, c), v in cal_w.items():
+    if "k_fill" in k and c == "WRITE_SIZE":
+        summary["calibration"]["k_fill (dwordx4 stores, known %d B)" % known] = {"WRITE_SIZE_KiB": sum(v) / len(v), "true/reported": known / (sum(v) / len(v) * 1024)}
+if fetch_factor is None:
+    fetch_factor = 2.0
+fetch, write = counters(f"{tag}_fetch"), counters(f"{tag}_write")
+per_kernel = collections.defaultdict(dict)
+for (k, c), v in list(fetch.items()) + list(write.items()):
+    if "d2pc::" in k:
+        per_kernel[k][c] = sum(v) / len(v)
+        per_kernel[k]["launches_" + c] = len(v)
+traffic = {}
+for k, d in per_kernel.items():
+    d["read_bytes"] = d.get("FETCH_SIZE", 0) * 1024 * round(fetch_factor, 3)
+    d["write_bytes"] = d.get("WRITE_SIZE", 0) * 1024
+    d["hbm_bytes_per_launch"] = d["read_bytes"] + d["write_bytes"]
+    summary["kernels"][k] = d
+json.dump(summary, open(os.path.join(dst, f"{rnd}_pmc_summary.json"), "w"), indent=1)
+
+# bench.py keys: "<mode>_border<b>_frames<n>"; the profiled run is the default bench config
+main = [k for k in per_kernel if "k_reproject_pack" in k]
+if main:
+    # the default config launches the VEC stereo kernel 5+1+... times; variants use the same kernel with border 0,
+    # so take the FIRST dispatches (main run) from the raw CSV instead of the mean
+    f = one(f"{tag}_fetch/*/*_counter_collection.csv"); w = one(f"{tag}_write/*/*_counter_collection.csv")
+    def first_n(path, ctr, n=6):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "k_reproject_pack" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+        return vals[:n]
+    fv, wv = first_n(f, "FETCH_SIZE"), first_n(w, "WRITE_SIZE")
+    rb = sum(fv) / len(fv) * 1024 * round(fetch_factor, 3); wb = sum(wv) / len(wv) * 1024
+    traffic["parity_border40_frames16"] = {
+        "hbm_bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb,
+        "source": f"profiles/{rnd}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                  f"FETCH_SIZE x{round(fetch_factor,3)} per calibration)"}
+    json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1)[:3000])
+print(json.dumps(traffic, indent=1))

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--modes", default="parity,compact")
     ap.add_argument("--borders", default="40,0")
     ap.add_argument("--algos", default="1,2")
+    ap.add_argument("--novec", type=int, default=0)
     a = ap.parse_args()
     q = d2pc.make_q()
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -57,13 +58,14 @@ def main():
                     npts = int(b.counts.sum().item())
                     rin = a.frames * b.roi_n
                     alg_bytes = 4 * rin + (20 if idx else 16) * npts
-                    for pxt, bpc, gen in [(p, b, 0) for p in (4, 8, 16) for b in (4, 6, 8, 16)] + [(8, 16, 1)]:
+                    for pxt, bpc, gen, novec in [(p, b, 0, nv) for p in (8, 16) for b in (8, 16) for nv in (0, 1)] + [(8, 16, 1, 0)]:
                         if True:
                             ctx.set_tuning("force_general_q", gen)
+                            ctx.set_tuning("no_vec_rows", novec)
                             ctx.set_tuning("pxt_parity" if mode == d2pc.MODE_PARITY else "pxt_compact", pxt)
                             ctx.set_tuning("blocks_per_cu", bpc)
                             med, mn = time_launch(b)
-                            print(f"{name:7s} border={border:2d} algo={algo} idx={int(idx)} pxt={pxt:2d} bpc={bpc:2d} gen={gen} "
+                            print(f"{name:7s} border={border:2d} algo={algo} idx={int(idx)} pxt={pxt:2d} bpc={bpc:2d} gen={gen} novec={novec} "
                                   f"med={med*1e3:8.1f}us min={mn*1e3:8.1f}us  {alg_bytes/med/1e6:7.1f} GB/s "
                                   f"{a.frames*a.w*a.h/med/1e3:8.1f} Mpix/s pts={npts}", flush=True)
                     if mode == d2pc.MODE_COMPACT:
