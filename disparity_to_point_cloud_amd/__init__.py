@@ -17,6 +17,8 @@ from .capi import (  # noqa: F401
     MODE_COMPACT,
     CALIB_BLOB_BYTES,
     abi_version,
+    calib_pack,
+    calib_unpack,
     device_count,
     library_path,
     load_library,

@@ -18,6 +18,7 @@ CALIB_BLOB_BYTES = 136
 # every symbol include/d2pc.h declares (tests check the library exports all)
 ABI_SYMBOLS = [
     "d2pc_abi_version", "d2pc_status_string", "d2pc_device_count", "d2pc_make_q", "d2pc_config_init",
+    "d2pc_calib_pack", "d2pc_calib_unpack",
     "d2pc_create", "d2pc_destroy", "d2pc_last_error", "d2pc_set_q", "d2pc_get_q", "d2pc_set_border",
     "d2pc_set_mode", "d2pc_get_config", "d2pc_export_calibration", "d2pc_import_calibration",
     "d2pc_roi_points", "d2pc_cloud_meta_fill", "d2pc_process", "d2pc_process_device", "d2pc_reserve",
@@ -87,6 +88,8 @@ def load_library():
     L.d2pc_status_string.restype = cp
     L.d2pc_device_count.restype = ctypes.c_int
     L.d2pc_make_q.argtypes = [ctypes.c_double] * 5 + [ctypes.c_int, ctypes.c_int, dp]
+    L.d2pc_calib_pack.argtypes = [dp, ctypes.c_int, ctypes.c_int, vp]
+    L.d2pc_calib_unpack.argtypes = [vp, ctypes.c_size_t, dp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.d2pc_config_init.argtypes = [ctypes.POINTER(Config)]
     L.d2pc_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
     L.d2pc_destroy.argtypes = [vp]
@@ -145,6 +148,28 @@ def make_q(fx=714.24, fy=713.5, cx=376.0, cy=240.0, baseline=0.09, nx=752, ny=48
     if st:
         raise D2pcError(st, "d2pc_make_q")
     return q
+
+
+def calib_pack(q, border=40, mode=MODE_PARITY) -> bytes:
+    """Host-only: 16 x f64 Q + border + mode -> the 136-byte broadcast blob."""
+    q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(16))
+    buf = ctypes.create_string_buffer(CALIB_BLOB_BYTES)
+    st = load_library().d2pc_calib_pack(q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), border, mode, buf)
+    if st:
+        raise D2pcError(st, "d2pc_calib_pack")
+    return buf.raw
+
+
+def calib_unpack(blob: bytes):
+    """Host-only: blob -> (q[16] float64, border, mode)."""
+    q = np.zeros(16, dtype=np.float64)
+    b, m = ctypes.c_int(), ctypes.c_int()
+    buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+    st = load_library().d2pc_calib_unpack(buf, len(blob), q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                         ctypes.byref(b), ctypes.byref(m))
+    if st:
+        raise D2pcError(st, "d2pc_calib_unpack")
+    return q, b.value, m.value
 
 
 _NP2DT = {np.dtype(np.float32): DTYPE_F32, np.dtype(np.uint8): DTYPE_U8, np.dtype(np.uint16): DTYPE_U16}

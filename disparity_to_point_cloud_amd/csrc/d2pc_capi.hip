@@ -361,29 +361,46 @@ int d2pc_get_config(const d2pc_ctx *ctx, d2pc_config *cfg) {
   return D2PC_OK;
 }
 
-int d2pc_export_calibration(const d2pc_ctx *ctx, void *blob) {
-  if (!ctx || !blob) return D2PC_ERR_INVALID_ARG;
-  if (!ctx->have_q) return D2PC_ERR_NOT_CALIBRATED;
+// blob = 16 x f64 Q (bit copy: -0.0 survives) | int32 border | int32 mode, little-endian
+int d2pc_calib_pack(const double q[16], int border, int mode, void *blob) {
+  if (!q || !blob) return D2PC_ERR_INVALID_ARG;
+  if (border < 0 || border > 16384 || (mode != D2PC_MODE_PARITY && mode != D2PC_MODE_COMPACT)) return D2PC_ERR_INVALID_ARG;
   unsigned char *b = static_cast<unsigned char *>(blob);
-  memcpy(b, ctx->q, 128);
-  int32_t tail[2] = {ctx->cfg.border, ctx->cfg.mode};
+  memcpy(b, q, 128);
+  int32_t tail[2] = {border, mode};
   memcpy(b + 128, tail, 8);
   return D2PC_OK;
 }
 
-int d2pc_import_calibration(d2pc_ctx *ctx, const void *blob, size_t bytes) {
-  if (!ctx) return D2PC_ERR_INVALID_ARG;
-  if (!blob || bytes != D2PC_CALIB_BLOB_BYTES) return fail(ctx, D2PC_ERR_INVALID_ARG, "calibration blob must be %d bytes", D2PC_CALIB_BLOB_BYTES);
+int d2pc_calib_unpack(const void *blob, size_t bytes, double q[16], int *border, int *mode) {
+  if (!blob || !q || !border || !mode || bytes != D2PC_CALIB_BLOB_BYTES) return D2PC_ERR_INVALID_ARG;
   const unsigned char *b = static_cast<const unsigned char *>(blob);
   int32_t tail[2];
   memcpy(tail, b + 128, 8);
-  if (tail[0] < 0 || tail[0] > 16384 || (tail[1] != D2PC_MODE_PARITY && tail[1] != D2PC_MODE_COMPACT))
-    return fail(ctx, D2PC_ERR_INVALID_ARG, "calibration blob carries border %d mode %d", tail[0], tail[1]);
-  memcpy(ctx->q, b, 128);
+  if (tail[0] < 0 || tail[0] > 16384 || (tail[1] != D2PC_MODE_PARITY && tail[1] != D2PC_MODE_COMPACT)) return D2PC_ERR_INVALID_ARG;
+  memcpy(q, b, 128);
+  *border = tail[0];
+  *mode = tail[1];
+  return D2PC_OK;
+}
+
+int d2pc_export_calibration(const d2pc_ctx *ctx, void *blob) {
+  if (!ctx || !blob) return D2PC_ERR_INVALID_ARG;
+  if (!ctx->have_q) return D2PC_ERR_NOT_CALIBRATED;
+  return d2pc_calib_pack(ctx->q, ctx->cfg.border, ctx->cfg.mode, blob);
+}
+
+int d2pc_import_calibration(d2pc_ctx *ctx, const void *blob, size_t bytes) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  double q[16];
+  int border = 0, mode = 0;
+  if (d2pc_calib_unpack(blob, bytes, q, &border, &mode) != D2PC_OK)
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "bad calibration blob (must be %d bytes with a valid border/mode)", D2PC_CALIB_BLOB_BYTES);
+  memcpy(ctx->q, q, 128);
   ctx->have_q = true;
   classify_q(ctx);
-  ctx->cfg.border = tail[0];
-  ctx->cfg.mode = tail[1];
+  ctx->cfg.border = border;
+  ctx->cfg.mode = mode;
   return D2PC_OK;
 }
 

@@ -1,0 +1,140 @@
+// disparity_to_point_cloud_amd.hpp -- host-side mirror of the reference's
+// d2pc::Disparity2PCloud (include/disparity_to_point_cloud/
+// disparity_to_point_cloud.hpp:60-109, src/disparity_to_point_cloud.cpp:46-92)
+// with the reprojection + PCL pack (cpp:63-85) replaced by ONE call into the
+// C ABI (include/d2pc.h).  Same class name, same parameter names
+// (~fx_ ~fy_ ~cx_ ~cy_ ~base_line_), same defaults, same frame_id / stamp
+// rule, same hard-coded constants (median 11, scale 1/8, border 40), so a
+// node built from it drops into launch/d2pcloud.launch unchanged.
+//
+// Templated on a message policy `Msgs` { Image, PointCloud2, PointField,
+// static Mono8 prepare(const Image&, int median_ksize) }: the ROS adaptor
+// (ros/) instantiates it with sensor_msgs::* + cv_bridge/OpenCV, the ROS-free
+// harness with d2pc_shim::* (ros_shim.hpp) + image_prep.hpp.
+#pragma once
+#include <cstdio>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <string>
+
+#include "../include/d2pc.h"
+#include "image_prep.hpp"
+
+namespace d2pc {
+
+// nh_.param<double>(name, var, default) for the ROS-free build.
+struct ParamSource {
+  std::map<std::string, double> values;
+  void param(const std::string &name, double &var, double def) const {
+    auto it = values.find(name);
+    var = it == values.end() ? def : it->second;
+  }
+};
+
+template <class Msgs>
+class Disparity2PCloudT {
+ public:
+  typedef typename Msgs::Image Image;
+  typedef typename Msgs::PointCloud2 PointCloud2;
+  typedef typename Msgs::PointField PointField;
+  typedef std::function<void(const PointCloud2 &)> Publisher;  // p_cloud_pub_.publish
+
+ private:
+  // hpp:66-71
+  double fx_ = 714.24;
+  double fy_ = 713.5;
+  double cx_ = 376;
+  double cy_ = 240;
+  double base_line_ = 0.09;  // Omni-stereo
+  double Q_[16];             // hpp:72 (row-major 4x4)
+  d2pc_ctx *ctx_ = nullptr;
+  Publisher p_cloud_pub_;
+  bool verbose_ = false;
+
+ public:
+  // hpp:75-106.  `q_from_opencv`: the ROS adaptor passes the Q_ that
+  // cv::stereoRectify produced (hpp:104); without it the closed form of that
+  // call for this rig is used (d2pc_make_q).
+  Disparity2PCloudT(const ParamSource &nh, Publisher pub, int device_id = 0, const double *q_from_opencv = nullptr,
+                    int mode = D2PC_MODE_PARITY, bool verbose = false)
+      : p_cloud_pub_(std::move(pub)), verbose_(verbose) {
+    if (verbose_) printf("Constructor start\n");
+    nh.param("fx_", fx_, 714.24);
+    nh.param("fy_", fy_, 713.5);
+    nh.param("cx_", cx_, 376);
+    nh.param("cy_", cy_, 240);
+    nh.param("base_line_", base_line_, 0.09);
+    if (q_from_opencv) {
+      for (int i = 0; i < 16; ++i) Q_[i] = q_from_opencv[i];
+    } else if (d2pc_make_q(fx_, fy_, cx_, cy_, base_line_, 752, 480, Q_) != D2PC_OK) {  // hpp:101-104
+      throw std::runtime_error("bad calibration parameters");
+    }
+    if (verbose_) printf("stereoRectify\n");
+    d2pc_config cfg;
+    d2pc_config_init(&cfg);  // border 40 (cpp:70,72)
+    cfg.device_id = device_id;
+    cfg.mode = mode;
+    int st = d2pc_create(&cfg, &ctx_);
+    if (st != D2PC_OK) throw std::runtime_error(std::string("d2pc_create: ") + d2pc_status_string(st));
+    st = d2pc_set_q(ctx_, Q_);
+    if (st != D2PC_OK) throw std::runtime_error(std::string("d2pc_set_q: ") + d2pc_status_string(st));
+  }
+  ~Disparity2PCloudT() {
+    if (ctx_) d2pc_destroy(ctx_);
+  }
+  Disparity2PCloudT(const Disparity2PCloudT &) = delete;
+  Disparity2PCloudT &operator=(const Disparity2PCloudT &) = delete;
+
+  const double *Q() const { return Q_; }
+  d2pc_ctx *context() { return ctx_; }
+
+  // cpp:46-92
+  void DisparityCb(const typename Image::ConstPtr &msg) {
+    if (verbose_) printf("start \n");
+    // cpp:50     cv_bridge::toCvCopy(*msg, "mono8")
+    // cpp:55-57  cv::medianBlur(disparity->image, median_filtered, 11)
+    // stay on the host: Msgs::prepare is cv_bridge + OpenCV in the ROS build,
+    // image_prep.hpp in the ROS-free one
+    Mono8 median_filtered = Msgs::prepare(*msg, 11);
+    if (verbose_) printf("medianBlur \n");
+
+    // cpp:60-85: convertTo(CV_32FC1, 1/8) + reprojectImageTo3D + ROI loop +
+    // toROSMsg -- one C-ABI call, writing straight into output.data
+    PointCloud2 output;
+    const size_t cap = d2pc_roi_points(median_filtered.width, median_filtered.height, 40);
+    output.data.resize(cap * 16);
+    size_t n = 0;
+    const int st = d2pc_process(ctx_, median_filtered.pix.data(), D2PC_DTYPE_U8, 1.0f / 8.0f, median_filtered.width,
+                                median_filtered.height, size_t(median_filtered.width), output.data.data(), nullptr,
+                                cap, &n);
+    if (st != D2PC_OK)
+      throw std::runtime_error(std::string("d2pc_process: ") + d2pc_status_string(st) + ": " + d2pc_last_error(ctx_));
+    output.data.resize(n * 16);
+    if (verbose_) printf("Cloud size: %zu\n", n);  // cpp:82
+
+    // cpp:79-85: width = N, height = 1, is_dense = false, field table
+    d2pc_cloud_meta m;
+    d2pc_cloud_meta_fill(ctx_, n, &m);
+    output.height = m.height;
+    output.width = m.width;
+    output.point_step = m.point_step;
+    output.row_step = m.row_step;
+    output.is_bigendian = m.is_bigendian != 0;
+    output.is_dense = m.is_dense != 0;
+    output.fields.resize(m.n_fields);
+    for (uint32_t i = 0; i < m.n_fields; ++i) {
+      output.fields[i].name = m.fields[i].name;
+      output.fields[i].offset = m.fields[i].offset;
+      output.fields[i].datatype = m.fields[i].datatype;
+      output.fields[i].count = m.fields[i].count;
+    }
+    // cpp:87-90
+    output.header.stamp = msg->header.stamp;
+    output.header.frame_id = "/camera_optical_frame";
+    p_cloud_pub_(output);
+    if (verbose_) printf("publish\n");
+  }
+};
+
+}  // namespace d2pc

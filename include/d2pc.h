@@ -106,6 +106,11 @@ int d2pc_device_count(void);            /* number of HIP devices, 0 if none  */
 int d2pc_make_q(double fx, double fy, double cx, double cy, double baseline,
                 int nx, int ny, double q_out[16]);
 
+/* Host-only packing of the calibration blob (what rank 0 broadcasts): usable
+ * without a device, e.g. by the process that owns the ROS parameters. */
+int d2pc_calib_pack(const double q[16], int border, int mode, void *blob /*136 B*/);
+int d2pc_calib_unpack(const void *blob, size_t blob_bytes, double q_out[16], int *border, int *mode);
+
 /* ---- context ---------------------------------------------------------- */
 int d2pc_config_init(d2pc_config *cfg); /* reference defaults: border 40, PARITY */
 int d2pc_create(const d2pc_config *cfg, d2pc_ctx **out_ctx);

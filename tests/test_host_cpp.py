@@ -1,0 +1,81 @@
+"""The C++ host-side mirror of d2pc::Disparity2PCloud (host/), driven through
+the ROS-free replay harness.  CPU part: the plumbing the callback keeps on the
+host (cv_bridge::toCvCopy "mono8" semantics, medianBlur 11) against the
+oracle.  GPU part: the whole DisparityCb (BASELINE.json configs[0]: 640x480
+uint16 as mono16) against the oracle pipeline, byte for byte in metadata."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import assert_points_close, synth_disparity
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPLAY = os.path.join(ROOT, "host", "d2pc_replay")
+
+
+@pytest.fixture(scope="module")
+def replay():
+    if not os.path.exists(REPLAY):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "host")], check=True, capture_output=True)
+    return REPLAY
+
+
+def _run(replay, cmd, img, enc, tmp_path, *extra):
+    src, dst = tmp_path / "in.raw", tmp_path / "out.bin"
+    src.write_bytes(img.tobytes())
+    p = subprocess.run([replay, cmd, str(src), str(img.shape[1]), str(img.shape[0]), enc, str(dst), *extra],
+                       capture_output=True, text=True, timeout=120)
+    return p, dst
+
+
+def test_prep_mono8_and_mono16_match_oracle(replay, tmp_path):
+    rng = np.random.default_rng(17)
+    img8 = rng.integers(0, 256, size=(97, 131)).astype(np.uint8)
+    p, dst = _run(replay, "prep", img8, "mono8", tmp_path)
+    assert p.returncode == 0, p.stderr
+    got = np.frombuffer(dst.read_bytes(), dtype=np.uint8).reshape(img8.shape)
+    assert np.array_equal(got, oracle.median_u8(img8, 11))
+    img16 = rng.integers(0, 65536, size=(60, 83)).astype(np.uint16)  # arbitrary values: exercises the rounding
+    p, dst = _run(replay, "prep", img16, "mono16", tmp_path)
+    assert p.returncode == 0, p.stderr
+    got = np.frombuffer(dst.read_bytes(), dtype=np.uint8).reshape(img16.shape)
+    assert np.array_equal(got, oracle.median_u8(oracle.mono16_to_mono8(img16), 11))
+
+
+def test_non_colour_encoding_is_rejected_like_cv_bridge(replay, tmp_path):
+    img = np.ones((8, 8), dtype=np.float32)
+    p, _ = _run(replay, "prep", img, "32FC1", tmp_path)
+    assert p.returncode == 4 and "not a color format" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["parity", "compact"])
+def test_c1_full_callback_640x480_mono16(replay, tmp_path, mode):
+    import disparity_to_point_cloud_amd as d2pc
+
+    img = synth_disparity(1, 0, 640, 480, "mono16")
+    extra = ("compact",) if mode == "compact" else ()
+    p, dst = _run(replay, "cloud", img, "mono16", tmp_path, *extra)
+    assert p.returncode == 0, p.stderr
+    raw = dst.read_bytes()
+    meta, payload = raw.split(b"\n", 1)
+    kv = meta.decode().split()
+    m = dict(zip(kv[0:16:2], kv[1:16:2]))
+    pts = np.frombuffer(payload, dtype=np.float32).reshape(-1, 4)
+    # the oracle pipeline: toCvCopy(mono8) -> medianBlur 11 -> x1/8 -> reproject + ROI pack
+    q = d2pc.make_q()
+    med = oracle.median_u8(oracle.mono16_to_mono8(img), 11)
+    if mode == "parity":
+        want = oracle.reproject(med, q, border=40, scale=0.125)
+        assert len(pts) == 224000
+    else:
+        want, _ = oracle.reproject_compact(med, q, border=40, scale=0.125)
+    assert_points_close(pts, want, max_ulp=1, rel=1e-5, what="C1 callback")
+    n = len(want)
+    assert (m["height"], m["width"], m["point_step"], m["row_step"]) == ("1", str(n), "16", str(16 * n))
+    assert m["is_bigendian"] == "0" and m["is_dense"] == ("0" if mode == "parity" else "1")
+    assert m["frame_id"] == "/camera_optical_frame" and m["stamp"] == "1234.5678"
+    assert kv[kv.index("fields") + 1:] == ["x:0:7:1", "y:4:7:1", "z:8:7:1"]
