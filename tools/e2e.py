@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""End-to-end (PCIe-inclusive) rate of the host-buffer entry point d2pc_process:
+H2D copy + kernel + D2H copy per frame, synchronous.  Never the bench headline."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import disparity_to_point_cloud_amd as d2pc
+from disparity_to_point_cloud_amd.synth import synth_disparity
+q = d2pc.make_q()
+for (w, h) in ((640, 480), (752, 480), (1920, 1080), (3840, 2160)):
+    for mode, kind in ((d2pc.MODE_PARITY, "uniform"), (d2pc.MODE_COMPACT, "holes")):
+        fr = synth_disparity(4, 0, w, h, kind)
+        with d2pc.Context(q=q, mode=mode) as ctx:
+            import ctypes
+            cap = d2pc.roi_points(w, h, 40)
+            out = np.empty((cap, 4), dtype=np.float32)
+            n = ctypes.c_size_t()
+            L = d2pc.load_library()
+            def once():
+                st = L.d2pc_process(ctx.handle, fr.ctypes.data, 0, 1.0, w, h, fr.strides[0], out.ctypes.data, None, cap, ctypes.byref(n))
+                assert st == 0
+            for _ in range(3): once()
+            t0 = time.perf_counter(); k = 0
+            while time.perf_counter() - t0 < 1.0:
+                once(); k += 1
+            dt = (time.perf_counter() - t0) / k
+            print(f"{w}x{h} mode={'parity' if mode == 0 else 'compact'}: {dt*1e3:7.3f} ms/frame  {w*h/dt/1e6:8.1f} Mpix/s  "
+                  f"({(w*h*4 + n.value*16)/dt/1e9:5.1f} GB/s over PCIe, {n.value} points)", flush=True)
