@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "d2pc_create", "d2pc_destroy", "d2pc_last_error", "d2pc_set_q", "d2pc_get_q", "d2pc_set_border",
     "d2pc_set_mode", "d2pc_get_config", "d2pc_export_calibration", "d2pc_import_calibration",
     "d2pc_roi_points", "d2pc_cloud_meta_fill", "d2pc_process", "d2pc_process_device", "d2pc_reserve",
-    "d2pc_check_async_error", "d2pc_set_tuning",
+    "d2pc_check_async_error", "d2pc_set_tuning", "d2pc_median_device", "d2pc_process_mono8",
 ]
 
 
@@ -110,6 +110,10 @@ def load_library():
     L.d2pc_process_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, vp, ctypes.c_size_t, vp,
                                       vp]
+    L.d2pc_median_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                     vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp]
+    L.d2pc_process_mono8.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_float,
+                                     vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.d2pc_reserve.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.d2pc_check_async_error.argtypes = [vp]
     L.d2pc_set_tuning.argtypes = [vp, cp, ctypes.c_int]
@@ -285,6 +289,27 @@ class Context:
         if want_index:
             return out[: n.value], idx[: n.value]
         return out[: n.value]
+
+    def process_mono8(self, image: np.ndarray, median_ksize=11, scale=0.125, want_index=False, capacity=None):
+        """cpp:55-85 for one mono8 frame: device median -> x scale -> points."""
+        if image.ndim != 2 or image.dtype != np.uint8 or image.strides[1] != 1:
+            raise ValueError("image must be a 2-D uint8 array with contiguous rows")
+        h, w = image.shape
+        cfg = self.config()
+        cap = roi_points(w, h, cfg.border) if capacity is None else capacity
+        out = np.empty((max(cap, 1), 4), dtype=np.float32)
+        idx = np.empty(max(cap, 1), dtype=np.uint32) if want_index else None
+        n = ctypes.c_size_t(0)
+        st = self._L.d2pc_process_mono8(self._h, image.ctypes.data, w, h, image.strides[0], median_ksize, scale,
+                                        out.ctypes.data, idx.ctypes.data if want_index else None, cap, ctypes.byref(n))
+        self._check(st)
+        return (out[: n.value], idx[: n.value]) if want_index else out[: n.value]
+
+    def median_device(self, d_src_ptr, width, height, src_row_stride, src_frame_stride, n_frames, d_dst_ptr,
+                      dst_row_stride, dst_frame_stride, ksize=11, stream_ptr=None):
+        self._check(self._L.d2pc_median_device(self._h, d_src_ptr, width, height, src_row_stride, src_frame_stride,
+                                               n_frames, d_dst_ptr, dst_row_stride, dst_frame_stride, ksize,
+                                               stream_ptr))
 
     # -- hot path: device-resident batch (d2pc_process_device) --------------
     def process_device(self, d_disp_ptr, dtype, scale, width, height, row_stride, in_frame_stride, n_frames,

@@ -26,9 +26,10 @@ struct d2pc_ctx {
   double q[16] = {0};
   int q_kind = QK_GENERAL;
   QStereo qs{};
-  // tuning (d2pc_set_tuning); defaults from tools/tune.py on MI355X
-  int pxt_parity = 16, pxt_compact = 16;
-  int blocks_per_cu = 16;
+  // tuning (d2pc_set_tuning); defaults from tools/ab.py sweeps on MI355X
+  // (fast and slow devices agree on 2048-pixel tiles and 2-4 tiles per block)
+  int pxt_parity = 8, pxt_compact = 8;
+  int blocks_per_cu = 128;
   int force_general_q = 0;
   int no_vec_rows = 0;
   // device scratch
@@ -36,6 +37,7 @@ struct d2pc_ctx {
   void *d_in = nullptr;      size_t in_cap = 0;
   void *d_out = nullptr;     size_t out_cap = 0;
   void *d_idx = nullptr;     size_t idx_cap = 0;
+  void *d_med = nullptr;     size_t med_cap = 0;
   uint32_t *d_counts = nullptr;
   uint32_t *h_counts = nullptr;  // pinned
   char err[256] = {0};
@@ -170,8 +172,12 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     const double m = std::fmax(std::fabs(ctx->qs.f), std::fmax(mx, my));
     a.qs.w_safe = std::isfinite(m) ? std::ldexp(m, -126) : std::numeric_limits<double>::infinity();
   }
-  const uint32_t resident = uint32_t(ctx->cu_count) * uint32_t(ctx->blocks_per_cu);
-  a.grid = g.total_tiles < resident ? g.total_tiles : resident;
+  // grid: many more blocks than fit (the dispatcher keeps the CUs fed as blocks
+  // retire), each walking a few tiles: min(T, max(CUs*blocks_per_cu, T/4))
+  uint32_t want = uint32_t(ctx->cu_count) * uint32_t(ctx->blocks_per_cu);
+  const uint32_t quarter = (g.total_tiles + 3) / 4;
+  if (want < quarter) want = quarter;
+  a.grid = g.total_tiles < want ? g.total_tiles : want;
   if (a.grid == 0) a.grid = 1;
   if (ctx->cfg.mode == D2PC_MODE_PARITY) {
     a.pxt = ctx->pxt_parity;
@@ -316,6 +322,7 @@ int d2pc_destroy(d2pc_ctx *ctx) {
   if (ctx->d_in) (void)hipFree(ctx->d_in);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_idx) (void)hipFree(ctx->d_idx);
+  if (ctx->d_med) (void)hipFree(ctx->d_med);
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
   if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -436,7 +443,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   if (!ctx || !key) return D2PC_ERR_INVALID_ARG;
   if (!strcmp(key, "pxt_parity") && tile_shape_supported(value)) ctx->pxt_parity = value;
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
-  else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 64) ctx->blocks_per_cu = value;
+  else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
   else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
@@ -497,8 +504,11 @@ int d2pc_debug_read_header(d2pc_ctx *ctx, void *out64) {
 }
 #endif
 
-int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int width, int height,
-                 size_t row_stride, void *out_points, uint32_t *out_index, size_t capacity, size_t *n_points) {
+// Shared body of d2pc_process / d2pc_process_mono8: H2D copy (packed to a
+// 256-byte pitch), optional device median, kernel(s), D2H copy; synchronous.
+static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int width, int height,
+                              size_t row_stride, int median_ksize, void *out_points, uint32_t *out_index,
+                              size_t capacity, size_t *n_points) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
   if (n_points) *n_points = 0;
   if (!disp || !n_points) return fail(ctx, D2PC_ERR_INVALID_ARG, "null argument");
@@ -508,27 +518,39 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int wi
   const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
   if (dtype != D2PC_DTYPE_F32 && dtype != D2PC_DTYPE_U8 && dtype != D2PC_DTYPE_U16)
     return fail(ctx, D2PC_ERR_BAD_DTYPE, "dtype %d is not F32/U8/U16", dtype);
+  const bool median = median_ksize > 1;
+  if (median && (dtype != D2PC_DTYPE_U8 || !median_ksize_supported(median_ksize)))
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "median needs 8-bit input and an odd ksize in 3..11 (got %d)", median_ksize);
   const size_t es = elem_size(dtype);
   // device copy of the frame is packed to a 256-byte pitch
   const size_t pitch = (size_t(width > 0 ? width : 0) * es + 255) & ~size_t(255);
+  const int pxt = compact ? ctx->pxt_compact : ctx->pxt_parity;
   Geom g;
-  int st = make_geom(ctx, dtype, scale, width, height, row_stride, 0, 1, 0, compact ? ctx->pxt_compact : ctx->pxt_parity, &g);
+  int st = make_geom(ctx, dtype, scale, width, height, row_stride, 0, 1, 0, pxt, &g);
   if (st != D2PC_OK) return st;
   if (g.roi_n == 0) return D2PC_OK;  // cpp:70,72: empty loops => empty cloud
   if (!out_points) return fail(ctx, D2PC_ERR_INVALID_ARG, "out_points is null");
   if (!compact && capacity < g.roi_n)
     return fail(ctx, D2PC_ERR_CAPACITY, "capacity %zu < %u ROI points", capacity, g.roi_n);
   // the caller's stride is validated above; the kernel sees the packed copy
-  if ((st = make_geom(ctx, dtype, scale, width, height, pitch, 0, 1, 0, compact ? ctx->pxt_compact : ctx->pxt_parity,
-                      &g)) != D2PC_OK)
-    return st;
+  if ((st = make_geom(ctx, dtype, scale, width, height, pitch, 0, 1, 0, pxt, &g)) != D2PC_OK) return st;
   if ((st = grow(ctx, &ctx->d_in, &ctx->in_cap, pitch * size_t(height))) != D2PC_OK) return st;
+  if (median && (st = grow(ctx, &ctx->d_med, &ctx->med_cap, pitch * size_t(height))) != D2PC_OK) return st;
   if ((st = grow(ctx, &ctx->d_out, &ctx->out_cap, size_t(g.roi_n) * 16)) != D2PC_OK) return st;
   if (out_index && (st = grow(ctx, &ctx->d_idx, &ctx->idx_cap, size_t(g.roi_n) * 4)) != D2PC_OK) return st;
   hipStream_t s = ctx->stream;
   D2PC_HIP(ctx, hipMemcpy2DAsync(ctx->d_in, pitch, disp, row_stride, size_t(width) * es, size_t(height),
                                  hipMemcpyHostToDevice, s));
-  st = enqueue(ctx, g, ctx->d_in, dtype, ctx->d_out, out_index ? static_cast<uint32_t *>(ctx->d_idx) : nullptr,
+  const void *kernel_in = ctx->d_in;
+  if (median) {
+    MedianArgs m;
+    m.width = uint32_t(width);
+    m.height = uint32_t(height);
+    m.src_row_stride = m.dst_row_stride = uint32_t(pitch);
+    D2PC_HIP(ctx, launch_median(ctx->d_in, ctx->d_med, m, median_ksize, s));
+    kernel_in = ctx->d_med;
+  }
+  st = enqueue(ctx, g, kernel_in, dtype, ctx->d_out, out_index ? static_cast<uint32_t *>(ctx->d_idx) : nullptr,
                ctx->d_counts, s, true);
   if (st != D2PC_OK) return st;
   size_t n = g.roi_n;
@@ -545,6 +567,46 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int wi
   }
   D2PC_HIP(ctx, hipStreamSynchronize(s));
   *n_points = n;
+  return D2PC_OK;
+}
+
+int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int width, int height,
+                 size_t row_stride, void *out_points, uint32_t *out_index, size_t capacity, size_t *n_points) {
+  return process_host_frame(ctx, disp, dtype, scale, width, height, row_stride, 0, out_points, out_index, capacity,
+                            n_points);
+}
+
+int d2pc_process_mono8(d2pc_ctx *ctx, const uint8_t *image, int width, int height, size_t row_stride,
+                       int median_ksize, float scale, void *out_points, uint32_t *out_index, size_t capacity,
+                       size_t *n_points) {
+  return process_host_frame(ctx, image, D2PC_DTYPE_U8, scale, width, height, row_stride, median_ksize, out_points,
+                            out_index, capacity, n_points);
+}
+
+int d2pc_median_device(d2pc_ctx *ctx, const void *d_src, int width, int height, size_t src_row_stride,
+                       size_t src_frame_stride, int n_frames, void *d_dst, size_t dst_row_stride,
+                       size_t dst_frame_stride, int ksize, void *stream) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!d_src || !d_dst || d_src == d_dst) return fail(ctx, D2PC_ERR_INVALID_ARG, "bad device pointers");
+  if (!median_ksize_supported(ksize)) return fail(ctx, D2PC_ERR_INVALID_ARG, "ksize %d not in {3,5,7,9,11}", ksize);
+  if (width <= 0 || height <= 0 || n_frames <= 0 || n_frames > 65535)
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "bad size %dx%d x%d", width, height, n_frames);
+  if (src_row_stride < size_t(width) || dst_row_stride < size_t(width) || src_row_stride > 0xffffffffull ||
+      dst_row_stride > 0xffffffffull)
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "row stride smaller than the width");
+  if (n_frames > 1 && (src_frame_stride < size_t(height) * src_row_stride || dst_frame_stride < size_t(height) * dst_row_stride))
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "frame stride too small");
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  MedianArgs m;
+  m.width = uint32_t(width);
+  m.height = uint32_t(height);
+  m.n_frames = uint32_t(n_frames);
+  m.src_row_stride = uint32_t(src_row_stride);
+  m.dst_row_stride = uint32_t(dst_row_stride);
+  m.src_frame_stride = src_frame_stride;
+  m.dst_frame_stride = dst_frame_stride;
+  D2PC_HIP(ctx, launch_median(d_src, d_dst, m, ksize, static_cast<hipStream_t>(stream)));
   return D2PC_OK;
 }
 

@@ -78,7 +78,8 @@ enum : int { QK_GENERAL = 0, QK_STEREO = 1 };
 // ---- compaction state (zeroed by a memset node before every launch) -------
 //   [StateHeader 64 B][frame 0 state][frame 1 state]...
 //   frame state (frame_state_stride bytes, 256-B aligned):
-//     [ticket u32 on its own 64-B line][group_acc u64 x groups][granule u64 x tiles]
+//     [ticket u32 on its own 64-B line][group_acc u64 x groups][16 B x tiles]
+//   the 16 B per tile hold one u64 granule (single pass) or 4 x u32 wave counts (two-pass)
 //   group_acc = (tiles arrived << 32) | sum of their point counts
 //   granule   = kGranuleTag | point count of one tile
 struct StateHeader {

@@ -365,6 +365,9 @@ struct FrameState {
     group_acc = reinterpret_cast<uint64_t *>(fs + kFrameTicketBytes);
     granules = group_acc + g.groups_per_frame;
   }
+  // two-pass view of the granule area: 4 x uint32 per tile (per-wave counts,
+  // then the tile's exclusive prefix in word 0)
+  __device__ __forceinline__ uint32_t *partials() const { return reinterpret_cast<uint32_t *>(granules); }
 };
 
 __device__ __forceinline__ void backoff(uint32_t spins) {
@@ -456,78 +459,107 @@ __device__ __forceinline__ void tile_scatter(const TileRegs<DT, QK, PXT> &r, con
 template <int DT, int QK, int PXT, bool VEC>
 __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restrict__ disp, uint8_t *state,
                                                           const Geom g, const QArg<QK> Q) {
-  constexpr int WAVES = kBlock / 64;
-  __shared__ uint32_t s_w[WAVES];
+  // Counting needs no pixel order inside a tile, so there is no LDS, no
+  // barrier and no cross-wave reduction here: every WAVE leaves its own
+  // partial count (4 per tile); the scan kernel adds them up.
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  D2PC_DECLARE_STRIPS(VEC, wave);
   for (uint32_t t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
     const uint32_t f = fdiv(t, g.div_tpf);
     const uint32_t lt = t - f * g.tiles_per_frame;
     const uint32_t base = lt * uint32_t(kBlock * PXT);
     const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
     uint32_t c = 0;
-    if constexpr (QK == QK_STEREO) {
-      // predicate only: ~4 fp64 operations per pixel, the pass stays read-bound
-      TileIn<PXT> in;
-      tile_load<DT, PXT, VEC>(in, fin, g, base, wave, lane, wave_strip);
+    if constexpr (QK == QK_STEREO && VEC) {
+      // 16 B per lane straight from the rows; the exact predicate needs only d
+      // (~4 fp64 operations per pixel), so the pass stays read-bound
+      v4f q[PXT / 4];
+      uint32_t uu[PXT / 4], vv[PXT / 4];
+      Walker w4(g, base + wave * 256u + lane * 4u);
 #pragma unroll
-      for (int k = 0; k < PXT; ++k) {
-        const uint32_t i = slot_pixel(base, wave, lane, k);
-        const bool ok = (i < g.roi_n) && stereo_point_valid(Q, in.uu[k], in.vv[k], in.d[k], g.min_disparity);
-        c += uint32_t(__popcll(__ballot(ok)));
+      for (int j = 0; j < PXT / 4; ++j) {
+        uu[j] = w4.u + g.border;
+        vv[j] = w4.v + g.border;
+        const uint32_t off = vv[j] * g.row_stride + uu[j] * 4u;
+        const uint32_t last4 = g.last_off - 12u;
+        q[j] = ld(reinterpret_cast<const v4f *>(fin + (off < last4 ? off : last4)));
+        w4.step(g, g.s1024_v, g.s1024_u);
+      }
+#pragma unroll
+      for (int j = 0; j < PXT / 4; ++j) {
+        const uint32_t i0 = base + uint32_t(j) * 1024u + wave * 256u + lane * 4u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = (i0 + uint32_t(e) < g.roi_n) &&
+                          stereo_point_valid(Q, uu[j] + uint32_t(e), vv[j], q[j][e], g.min_disparity);
+          c += uint32_t(__popcll(__ballot(ok)));
+        }
       }
     } else {
-      TileRegs<DT, QK, PXT> r;
-      uint64_t mask[PXT];
-      tile_compute<DT, QK, PXT, VEC>(r, fin, g, Q, base, wave, lane, wave_strip);
-      tile_ballots<DT, QK, PXT>(r, g, base, wave, lane, mask);
+      float *wave_strip = nullptr;  // VEC staging is only worth it for the ordered passes
+      if constexpr (QK == QK_STEREO) {
+        TileIn<PXT> in;
+        tile_load<DT, PXT, false>(in, fin, g, base, wave, lane, wave_strip);
 #pragma unroll
-      for (int k = 0; k < PXT; ++k) c += uint32_t(__popcll(mask[k]));
+        for (int k = 0; k < PXT; ++k) {
+          const uint32_t i = slot_pixel(base, wave, lane, k);
+          const bool ok = (i < g.roi_n) && stereo_point_valid(Q, in.uu[k], in.vv[k], in.d[k], g.min_disparity);
+          c += uint32_t(__popcll(__ballot(ok)));
+        }
+      } else {
+        TileRegs<DT, QK, PXT> r;
+        uint64_t mask[PXT];
+        tile_compute<DT, QK, PXT, false>(r, fin, g, Q, base, wave, lane, wave_strip);
+        tile_ballots<DT, QK, PXT>(r, g, base, wave, lane, mask);
+#pragma unroll
+        for (int k = 0; k < PXT; ++k) c += uint32_t(__popcll(mask[k]));
+      }
     }
-    if (lane == 0) s_w[wave] = c;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t tot = 0;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) tot += s_w[w];
+    if (lane == 0) {
       const FrameState fs(state, g, f);
-      fs.granules[lt] = tot;  // plain store: the scan kernel reads it after the kernel boundary
+      fs.partials()[lt * 4u + wave] = c;  // plain store: read by k_compact_scan after the kernel boundary
     }
-    __syncthreads();
   }
 }
 
-// K2a': per-frame exclusive scan of the tile counts, in place (one block per
-// frame; a 4K frame has ~2-8 thousand tiles, i.e. a few microseconds).
+// K2a': per-frame exclusive scan of the tile counts (4 wave partials each),
+// one block per frame.  Every thread owns a run of consecutive tiles, so the
+// block synchronises once whatever the frame size (a 4K frame has 2-8
+// thousand tiles).  Leaves the exclusive prefix of tile i in partials[4*i].
 __global__ __launch_bounds__(kBlock) void k_compact_scan(uint8_t *state, uint32_t *__restrict__ counts,
                                                          const Geom g) {
   __shared__ uint32_t s_w[kBlock / 64];
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
   const FrameState fs(state, g, blockIdx.x);
-  uint32_t carry = 0;
-  for (uint32_t b = 0; b < g.tiles_per_frame; b += kBlock) {
-    const uint32_t i = b + tid;
-    const uint32_t c = i < g.tiles_per_frame ? uint32_t(fs.granules[i]) : 0u;
-    uint32_t incl = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t n = __shfl_up(incl, o, 64);
-      if (lane >= uint32_t(o)) incl += n;
-    }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
-      const uint32_t x = s_w[w];
-      before += uint32_t(w) < wave ? x : 0u;
-      total += x;
-    }
-    if (i < g.tiles_per_frame) fs.granules[i] = carry + before + incl - c;
-    carry += total;
-    __syncthreads();
+  const uint4 *part = reinterpret_cast<const uint4 *>(fs.partials());
+  const uint32_t per = (g.tiles_per_frame + kBlock - 1) / kBlock;
+  const uint32_t t0 = tid * per, t1 = t0 + per < g.tiles_per_frame ? t0 + per : g.tiles_per_frame;
+  uint32_t mine = 0;
+  for (uint32_t i = t0; i < t1; ++i) {
+    const uint4 p = part[i];
+    mine += p.x + p.y + p.z + p.w;
   }
-  if (tid == 0) counts[blockIdx.x] = carry;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t n = __shfl_up(incl, o, 64);
+    if (lane >= uint32_t(o)) incl += n;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const uint32_t x = s_w[w];
+    before += uint32_t(w) < wave ? x : 0u;
+    total += x;
+  }
+  uint32_t run = before + incl - mine;  // exclusive prefix of this thread's first tile
+  for (uint32_t i = t0; i < t1; ++i) {
+    const uint4 p = part[i];
+    fs.partials()[4u * i] = run;
+    run += p.x + p.y + p.z + p.w;
+  }
+  if (tid == 0) counts[blockIdx.x] = total;
 }
 
 template <int DT, int QK, int PXT, bool VEC>
@@ -556,7 +588,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
     uint32_t total;
     const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
     const FrameState fs(state, g, f);
-    const uint32_t prefix = uint32_t(fs.granules[lt]);  // exclusive prefix left by k_compact_scan (uniform load)
+    const uint32_t prefix = fs.partials()[4u * lt];  // exclusive prefix left by k_compact_scan (uniform load)
     float4 *fout = out + uint64_t(f) * g.out_frame_stride;
     uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
     tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane, g.roi_n);
@@ -746,7 +778,7 @@ bool tile_shape_supported(int pxt) { return pxt == 4 || pxt == 8 || pxt == 16; }
 
 uint32_t frame_state_stride(uint32_t tiles_per_frame) {
   const uint32_t groups = (tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
-  const uint64_t b = kFrameTicketBytes + uint64_t(groups + tiles_per_frame) * 8;
+  const uint64_t b = kFrameTicketBytes + uint64_t(groups) * 8 + uint64_t(tiles_per_frame) * 16;
   return uint32_t((b + 255) & ~uint64_t(255));
 }
 

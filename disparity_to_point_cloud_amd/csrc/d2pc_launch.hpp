@@ -29,6 +29,16 @@ struct LaunchArgs {
   QStereo qs{};
 };
 
+// k x k median of 8-bit frames (d2pc_median.hip)
+struct MedianArgs {
+  uint32_t width = 0, height = 0, n_frames = 1;
+  uint32_t src_row_stride = 0, dst_row_stride = 0;  // bytes
+  uint64_t src_frame_stride = 0, dst_frame_stride = 0;
+  uint32_t tiles_x = 0, tiles_y = 0;                // filled by launch_median
+};
+bool median_ksize_supported(int k);
+hipError_t launch_median(const void *src, void *dst, const MedianArgs &a, int ksize, hipStream_t stream);
+
 bool tile_shape_supported(int pxt);
 uint32_t frame_state_stride(uint32_t tiles_per_frame);
 size_t compact_state_bytes(const Geom &g);

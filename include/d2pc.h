@@ -167,6 +167,30 @@ int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype,
                         size_t out_frame_stride_points, uint32_t *d_counts,
                         void *stream);
 
+/*
+ * The rest of the callback body on the device:
+ * k x k median of 8-bit frames with replicated borders, i.e.
+ * cv::medianBlur(image, filtered, 11) at cpp:55-57.  ksize odd, 3..11.
+ * Device-resident, batched, asynchronous on `stream` like
+ * d2pc_process_device; src and dst must not overlap.
+ */
+int d2pc_median_device(d2pc_ctx *ctx, const void *d_src, int width, int height,
+                       size_t src_row_stride_bytes, size_t src_frame_stride_bytes,
+                       int n_frames, void *d_dst, size_t dst_row_stride_bytes,
+                       size_t dst_frame_stride_bytes, int ksize, void *stream);
+
+/*
+ * cpp:55-85 in one call for one mono8 frame in HOST memory (what
+ * cv_bridge::toCvCopy(msg,"mono8") returned, cpp:50): median (median_ksize,
+ * the reference uses 11; 0 or 1 = none) -> x scale (1/8, cpp:61) ->
+ * reprojection + ROI pack.  Only 1 byte per pixel crosses PCIe on the way in.
+ * Other arguments as d2pc_process.
+ */
+int d2pc_process_mono8(d2pc_ctx *ctx, const uint8_t *image, int width, int height,
+                       size_t row_stride_bytes, int median_ksize, float scale,
+                       void *out_points, uint32_t *out_index,
+                       size_t capacity_points, size_t *n_points);
+
 /* Pre-size the context's scratch (tile state, staging) for frames up to
  * width x height and batches up to n_frames. */
 int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames);
@@ -177,7 +201,7 @@ int d2pc_check_async_error(d2pc_ctx *ctx);
 
 /* Launch-shape tuning hook (no counterpart in the reference; results never
  * depend on it).  Keys: "pxt_parity", "pxt_compact" (ROI pixels per thread:
- * 4, 8 or 16), "blocks_per_cu" (resident 256-thread blocks per CU, 1..64). */
+ * 4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by the tile count; 1..4096). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus
