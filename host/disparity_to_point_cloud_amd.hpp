@@ -51,14 +51,15 @@ class Disparity2PCloudT {
   d2pc_ctx *ctx_ = nullptr;
   Publisher p_cloud_pub_;
   bool verbose_ = false;
+  bool gpu_median_ = true;  // cpp:55-57 on the device (d2pc_process_mono8) or on the host (Msgs::prepare)
 
  public:
   // hpp:75-106.  `q_from_opencv`: the ROS adaptor passes the Q_ that
   // cv::stereoRectify produced (hpp:104); without it the closed form of that
   // call for this rig is used (d2pc_make_q).
   Disparity2PCloudT(const ParamSource &nh, Publisher pub, int device_id = 0, const double *q_from_opencv = nullptr,
-                    int mode = D2PC_MODE_PARITY, bool verbose = false)
-      : p_cloud_pub_(std::move(pub)), verbose_(verbose) {
+                    int mode = D2PC_MODE_PARITY, bool verbose = false, bool gpu_median = true)
+      : p_cloud_pub_(std::move(pub)), verbose_(verbose), gpu_median_(gpu_median) {
     if (verbose_) printf("Constructor start\n");
     nh.param("fx_", fx_, 714.24);
     nh.param("fy_", fy_, 713.5);
@@ -92,11 +93,12 @@ class Disparity2PCloudT {
   // cpp:46-92
   void DisparityCb(const typename Image::ConstPtr &msg) {
     if (verbose_) printf("start \n");
-    // cpp:50     cv_bridge::toCvCopy(*msg, "mono8")
+    // cpp:50     cv_bridge::toCvCopy(*msg, "mono8")            -- always on the host
     // cpp:55-57  cv::medianBlur(disparity->image, median_filtered, 11)
-    // stay on the host: Msgs::prepare is cv_bridge + OpenCV in the ROS build,
-    // image_prep.hpp in the ROS-free one
-    Mono8 median_filtered = Msgs::prepare(*msg, 11);
+    //            on the host (Msgs::prepare(msg, 11): cv_bridge + OpenCV in the
+    //            ROS build, image_prep.hpp in the ROS-free one), or on the
+    //            device inside d2pc_process_mono8 (then prepare only decodes)
+    Mono8 median_filtered = Msgs::prepare(*msg, gpu_median_ ? 1 : 11);
     if (verbose_) printf("medianBlur \n");
 
     // cpp:60-85: convertTo(CV_32FC1, 1/8) + reprojectImageTo3D + ROI loop +
@@ -105,11 +107,12 @@ class Disparity2PCloudT {
     const size_t cap = d2pc_roi_points(median_filtered.width, median_filtered.height, 40);
     output.data.resize(cap * 16);
     size_t n = 0;
-    const int st = d2pc_process(ctx_, median_filtered.pix.data(), D2PC_DTYPE_U8, 1.0f / 8.0f, median_filtered.width,
-                                median_filtered.height, size_t(median_filtered.width), output.data.data(), nullptr,
-                                cap, &n);
+    const int st = d2pc_process_mono8(ctx_, median_filtered.pix.data(), median_filtered.width, median_filtered.height,
+                                      size_t(median_filtered.width), gpu_median_ ? 11 : 0, 1.0f / 8.0f,
+                                      output.data.data(), nullptr, cap, &n);
     if (st != D2PC_OK)
-      throw std::runtime_error(std::string("d2pc_process: ") + d2pc_status_string(st) + ": " + d2pc_last_error(ctx_));
+      throw std::runtime_error(std::string("d2pc_process_mono8: ") + d2pc_status_string(st) + ": " +
+                               d2pc_last_error(ctx_));
     output.data.resize(n * 16);
     if (verbose_) printf("Cloud size: %zu\n", n);  // cpp:82
 

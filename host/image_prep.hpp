@@ -58,6 +58,7 @@ Mono8 to_mono8(const Image &msg) {
 // k x k median on 8-bit, BORDER_REPLICATE (what cv::medianBlur computes):
 // per row a sliding 256-bin histogram, k column taps leave and k enter per step.
 inline Mono8 median_blur(const Mono8 &src, int ksize) {
+  if (ksize <= 1) return src;
   Mono8 dst;
   dst.width = src.width;
   dst.height = src.height;

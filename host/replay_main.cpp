@@ -1,7 +1,7 @@
 // replay_main.cpp -- ROS-free harness around Disparity2PCloud::DisparityCb.
 //   d2pc_replay prep  <in.raw> <w> <h> <mono8|mono16> <out.raw>
 //        host plumbing only (toCvCopy + medianBlur 11): no GPU needed
-//   d2pc_replay cloud <in.raw> <w> <h> <mono8|mono16> <out.bin> [compact]
+//   d2pc_replay cloud <in.raw> <w> <h> <mono8|mono16> <out.bin> [compact] [hostmedian]
 //        full callback; writes PointCloud2 metadata (text) then the payload
 // <in.raw> holds the sensor_msgs/Image data bytes (row-major, step = w*bpp).
 #include <cstdio>
@@ -18,6 +18,12 @@ static std::vector<uint8_t> slurp(const char *path) {
   std::ifstream f(path, std::ios::binary);
   if (!f) { fprintf(stderr, "cannot read %s\n", path); exit(2); }
   return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static bool has_flag(int argc, char **argv, const char *flag) {
+  for (int i = 7; i < argc; ++i)
+    if (!strcmp(argv[i], flag)) return true;
+  return false;
 }
 
 int main(int argc, char **argv) {
@@ -44,7 +50,8 @@ int main(int argc, char **argv) {
       d2pc::ParamSource nh;  // d2pcloud.launch sets no params: defaults apply
       d2pc::Disparity2PCloudT<d2pc_shim::Msgs> node(
           nh, [&](const d2pc_shim::PointCloud2 &pc) { got = pc; ++published; }, 0, nullptr,
-          argc > 7 && !strcmp(argv[7], "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY);
+          has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false,
+          !has_flag(argc, argv, "hostmedian"));
       node.DisparityCb(img);
       if (published != 1) { fprintf(stderr, "nothing published\n"); return 3; }
       std::ofstream o(argv[6], std::ios::binary);

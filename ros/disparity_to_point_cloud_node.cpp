@@ -24,7 +24,8 @@ struct RosMsgs {
   static d2pc::Mono8 prepare(const Image &msg, int median_ksize) {
     cv_bridge::CvImagePtr disparity = cv_bridge::toCvCopy(msg, "mono8");          // cpp:50
     cv::Mat median_filtered(disparity->image.size(), CV_8U);
-    cv::medianBlur(disparity->image, median_filtered, median_ksize);               // cpp:55-57
+    if (median_ksize > 1) cv::medianBlur(disparity->image, median_filtered, median_ksize);  // cpp:55-57 (host median)
+    else median_filtered = disparity->image.clone();                                        // median runs on the GPU
     d2pc::Mono8 out;
     out.width = median_filtered.cols;
     out.height = median_filtered.rows;

@@ -52,12 +52,13 @@ def test_non_colour_encoding_is_rejected_like_cv_bridge(replay, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("median", ["gpu", "hostmedian"])
 @pytest.mark.parametrize("mode", ["parity", "compact"])
-def test_c1_full_callback_640x480_mono16(replay, tmp_path, mode):
+def test_c1_full_callback_640x480_mono16(replay, tmp_path, mode, median):
     import disparity_to_point_cloud_amd as d2pc
 
     img = synth_disparity(1, 0, 640, 480, "mono16")
-    extra = ("compact",) if mode == "compact" else ()
+    extra = (("compact",) if mode == "compact" else ()) + (("hostmedian",) if median == "hostmedian" else ())
     p, dst = _run(replay, "cloud", img, "mono16", tmp_path, *extra)
     assert p.returncode == 0, p.stderr
     raw = dst.read_bytes()

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Time the device median and the whole device-resident callback body
+(median 11 -> x1/8 -> reproject+pack) on batches of 8-bit frames. GPU only."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import disparity_to_point_cloud_amd as d2pc
+from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+
+def t(fn, iters=10, rounds=5):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): fn()
+        e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / iters * 1e3)
+    return float(np.median(ts))
+
+q = d2pc.make_q()
+s = torch.cuda.current_stream().cuda_stream
+for (w, h, n) in ((752, 480, 64), (1920, 1080, 16), (3840, 2160, 16)):
+    ctx = d2pc.Context(q=q)
+    raw = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device="cuda")
+    b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8)
+    for k in (3, 11):
+        us = t(lambda: ctx.median_device(raw.data_ptr(), w, h, w, w * h, n, b.disp.data_ptr(), w, w * h, k, s))
+        print(f"{w}x{h} x{n}: median{k:2d} {us:8.1f} us  = {us/n:7.2f} us/frame  {n*w*h/us:9.1f} Mpix/s", flush=True)
+    def body():
+        ctx.median_device(raw.data_ptr(), w, h, w, w * h, n, b.disp.data_ptr(), w, w * h, 11, s)
+        b.launch(scale=0.125)
+    us = t(body)
+    us_r = t(lambda: b.launch(scale=0.125))
+    print(f"{w}x{h} x{n}: callback body (median11 + reproject u8) {us:8.1f} us = {us/n:7.2f} us/frame {n*w*h/us:9.1f} Mpix/s; reproject alone {us_r:8.1f} us", flush=True)
+    ctx.close()
