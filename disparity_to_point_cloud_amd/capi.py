@@ -23,6 +23,8 @@ ABI_SYMBOLS = [
     "d2pc_set_mode", "d2pc_get_config", "d2pc_export_calibration", "d2pc_import_calibration",
     "d2pc_roi_points", "d2pc_cloud_meta_fill", "d2pc_process", "d2pc_process_device", "d2pc_reserve",
     "d2pc_check_async_error", "d2pc_set_tuning", "d2pc_median_device", "d2pc_process_mono8",
+    "d2pc_pipeline_configure", "d2pc_pipeline_acquire", "d2pc_pipeline_submit", "d2pc_pipeline_collect",
+    "d2pc_pipeline_release",
 ]
 
 
@@ -48,6 +50,14 @@ class CloudMeta(ctypes.Structure):
         ("height", ctypes.c_uint32), ("width", ctypes.c_uint32), ("point_step", ctypes.c_uint32),
         ("row_step", ctypes.c_uint32), ("is_bigendian", ctypes.c_uint8), ("is_dense", ctypes.c_uint8),
         ("n_fields", ctypes.c_uint32), ("fields", Field * 3),
+    ]
+
+
+class FrameDesc(ctypes.Structure):
+    _fields_ = [
+        ("dtype", ctypes.c_int32), ("scale", ctypes.c_float), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("row_stride_bytes", ctypes.c_size_t), ("median_ksize", ctypes.c_int32), ("want_index", ctypes.c_int32),
+        ("tag", ctypes.c_uint64),
     ]
 
 
@@ -114,6 +124,12 @@ def load_library():
                                      vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp]
     L.d2pc_process_mono8.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_float,
                                      vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.d2pc_pipeline_configure.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.d2pc_pipeline_acquire.argtypes = [vp, ctypes.POINTER(FrameDesc), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
+    L.d2pc_pipeline_submit.argtypes = [vp, ctypes.c_int]
+    L.d2pc_pipeline_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint64)]
+    L.d2pc_pipeline_release.argtypes = [vp, ctypes.c_int]
     L.d2pc_reserve.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.d2pc_check_async_error.argtypes = [vp]
     L.d2pc_set_tuning.argtypes = [vp, cp, ctypes.c_int]
@@ -310,6 +326,45 @@ class Context:
         self._check(self._L.d2pc_median_device(self._h, d_src_ptr, width, height, src_row_stride, src_frame_stride,
                                                n_frames, d_dst_ptr, dst_row_stride, dst_frame_stride, ksize,
                                                stream_ptr))
+
+    # -- pipelined host path (d2pc_pipeline_*) ------------------------------
+    def pipeline_configure(self, depth=3, direct_host_write=False):
+        self._check(self._L.d2pc_pipeline_configure(self._h, depth, int(direct_host_write)))
+
+    def pipeline_submit(self, image: np.ndarray, scale=1.0, median_ksize=0, want_index=False, tag=0) -> int:
+        """Acquire a slot, copy `image` into its pinned input buffer (a real
+        producer would decode straight into it) and submit.  Returns the slot."""
+        dt = _NP2DT[image.dtype]
+        h, w = image.shape
+        desc = FrameDesc(dt, scale, w, h, w * image.itemsize, median_ksize, int(want_index), tag)
+        host_in, slot = ctypes.c_void_p(), ctypes.c_int()
+        self._check(self._L.d2pc_pipeline_acquire(self._h, ctypes.byref(desc), ctypes.byref(host_in), ctypes.byref(slot)))
+        dst = np.ctypeslib.as_array(ctypes.cast(host_in, ctypes.POINTER(ctypes.c_uint8)), shape=(h * w * image.itemsize,))
+        dst[:] = np.ascontiguousarray(image).view(np.uint8).reshape(-1)
+        self._check(self._L.d2pc_pipeline_submit(self._h, slot.value))
+        return slot.value
+
+    def pipeline_collect(self, copy=True):
+        """Oldest submitted frame -> (points, index or None, tag, slot).  With
+        copy=False the arrays are VIEWS of the pinned buffers, valid until
+        pipeline_release(slot)."""
+        slot, pts, idx = ctypes.c_int(), ctypes.c_void_p(), ctypes.c_void_p()
+        n, tag = ctypes.c_size_t(), ctypes.c_uint64()
+        self._check(self._L.d2pc_pipeline_collect(self._h, ctypes.byref(slot), ctypes.byref(pts), ctypes.byref(idx),
+                                                  ctypes.byref(n), ctypes.byref(tag)))
+        if n.value:
+            p = np.ctypeslib.as_array(ctypes.cast(pts, ctypes.POINTER(ctypes.c_float)), shape=(n.value, 4))
+            i = (np.ctypeslib.as_array(ctypes.cast(idx, ctypes.POINTER(ctypes.c_uint32)), shape=(n.value,))
+                 if idx.value else None)
+        else:
+            p, i = np.empty((0, 4), np.float32), (np.empty(0, np.uint32) if idx.value else None)
+        if copy:
+            p, i = p.copy(), (i.copy() if i is not None else None)
+            self.pipeline_release(slot.value)
+        return p, i, tag.value, slot.value
+
+    def pipeline_release(self, slot: int):
+        self._check(self._L.d2pc_pipeline_release(self._h, slot))
 
     # -- hot path: device-resident batch (d2pc_process_device) --------------
     def process_device(self, d_disp_ptr, dtype, scale, width, height, row_stride, in_frame_stride, n_frames,

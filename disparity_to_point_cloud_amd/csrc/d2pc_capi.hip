@@ -17,6 +17,25 @@
 
 using namespace d2pc;
 
+// One frame in flight on the pipelined host path (d2pc_pipeline_*).
+struct PipeSlot {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  void *h_in = nullptr;      size_t h_in_cap = 0;    // pinned; the caller fills it
+  void *h_out = nullptr;     size_t h_out_cap = 0;   // pinned; points (+ index behind them)
+  uint32_t *h_count = nullptr;                       // pinned
+  void *d_in = nullptr;      size_t d_in_cap = 0;
+  void *d_med = nullptr;     size_t d_med_cap = 0;
+  void *d_out = nullptr;     size_t d_out_cap = 0;
+  void *d_idx = nullptr;     size_t d_idx_cap = 0;
+  void *d_state = nullptr;   size_t d_state_cap = 0;
+  uint32_t *d_count = nullptr;
+  d2pc_frame_desc desc{};
+  size_t roi_n = 0, idx_off = 0;
+  int state = 0;             // 0 free, 1 acquired, 2 submitted, 3 collected (until release)
+  uint64_t seq = 0;
+};
+
 struct d2pc_ctx {
   d2pc_config cfg{};
   int device = 0;
@@ -40,6 +59,11 @@ struct d2pc_ctx {
   void *d_med = nullptr;     size_t med_cap = 0;
   uint32_t *d_counts = nullptr;
   uint32_t *h_counts = nullptr;  // pinned
+  // pipelined host path
+  PipeSlot slots[8];
+  int pipe_depth = 0;
+  int pipe_direct = 0;           // kernels write straight into pinned host memory
+  uint64_t pipe_seq = 0;
   char err[256] = {0};
 };
 
@@ -147,7 +171,12 @@ int make_geom(d2pc_ctx *ctx, int dtype, float scale, int width, int height, size
 }
 
 int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d_out, uint32_t *d_idx,
-            uint32_t *d_counts, hipStream_t stream, bool allow_alloc) {
+            uint32_t *d_counts, hipStream_t stream, bool allow_alloc, void **state_buf = nullptr,
+            size_t *state_cap = nullptr) {
+  if (!state_buf) {
+    state_buf = &ctx->d_state;
+    state_cap = &ctx->state_cap;
+  }
   LaunchArgs a;
   a.disp = d_disp;
   a.out_points = d_out;
@@ -188,12 +217,12 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   a.pxt = ctx->pxt_compact;
   a.compact_algo = ctx->cfg.compact_algo == 2 ? 2 : 1;  // default: two-pass (faster today, no spin-waits)
   a.state_bytes = compact_state_bytes(g);
-  if (a.state_bytes > ctx->state_cap) {
+  if (a.state_bytes > *state_cap) {
     if (!allow_alloc) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "compaction state not reserved (call d2pc_reserve)");
-    int st = grow(ctx, &ctx->d_state, &ctx->state_cap, a.state_bytes);
+    int st = grow(ctx, state_buf, state_cap, a.state_bytes);
     if (st != D2PC_OK) return st;
   }
-  a.state = ctx->d_state;
+  a.state = *state_buf;
   D2PC_HIP(ctx, launch_compact(a));
   return D2PC_OK;
 }
@@ -325,6 +354,20 @@ int d2pc_destroy(d2pc_ctx *ctx) {
   if (ctx->d_med) (void)hipFree(ctx->d_med);
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
   if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+  for (PipeSlot &sl : ctx->slots) {
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    if (sl.h_in) (void)hipHostFree(sl.h_in);
+    if (sl.h_out) (void)hipHostFree(sl.h_out);
+    if (sl.h_count) (void)hipHostFree(sl.h_count);
+    if (sl.d_in) (void)hipFree(sl.d_in);
+    if (sl.d_med) (void)hipFree(sl.d_med);
+    if (sl.d_out) (void)hipFree(sl.d_out);
+    if (sl.d_idx) (void)hipFree(sl.d_idx);
+    if (sl.d_state) (void)hipFree(sl.d_state);
+    if (sl.d_count) (void)hipFree(sl.d_count);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return D2PC_OK;
@@ -607,6 +650,168 @@ int d2pc_median_device(d2pc_ctx *ctx, const void *d_src, int width, int height, 
   m.src_frame_stride = src_frame_stride;
   m.dst_frame_stride = dst_frame_stride;
   D2PC_HIP(ctx, launch_median(d_src, d_dst, m, ksize, static_cast<hipStream_t>(stream)));
+  return D2PC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Pipelined host path: up to `depth` frames in flight, each on its own stream
+// with its own pinned staging, so the H2D copy of frame i+1, the kernels of
+// frame i and the D2H copy of frame i-1 overlap (PCIe is full duplex).
+// ---------------------------------------------------------------------------
+static int grow_pinned(d2pc_ctx *ctx, void **p, size_t *cap, size_t need) {
+  if (need <= *cap) return D2PC_OK;
+  if (*p) {
+    D2PC_HIP(ctx, hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+  }
+  const size_t want = (need + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+  D2PC_HIP(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
+  *cap = want;
+  return D2PC_OK;
+}
+
+int d2pc_pipeline_configure(d2pc_ctx *ctx, int depth, int direct_host_write) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (depth < 1 || depth > 8) return fail(ctx, D2PC_ERR_INVALID_ARG, "pipeline depth %d not in 1..8", depth);
+  for (const PipeSlot &sl : ctx->slots)
+    if (sl.state != 0) return fail(ctx, D2PC_ERR_INVALID_ARG, "frames are still in flight");
+  DeviceGuard guard(ctx->device);
+  for (int i = 0; i < depth; ++i) {
+    PipeSlot &sl = ctx->slots[i];
+    if (!sl.stream) D2PC_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    if (!sl.done) D2PC_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (!sl.d_count) D2PC_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.d_count), 64));
+    if (!sl.h_count) D2PC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_count), 64, hipHostMallocDefault));
+  }
+  ctx->pipe_depth = depth;
+  ctx->pipe_direct = direct_host_write ? 1 : 0;
+  return D2PC_OK;
+}
+
+int d2pc_pipeline_acquire(d2pc_ctx *ctx, const d2pc_frame_desc *desc, void **host_in, int *slot) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!desc || !host_in || !slot) return fail(ctx, D2PC_ERR_INVALID_ARG, "null argument");
+  if (ctx->pipe_depth == 0) return fail(ctx, D2PC_ERR_INVALID_ARG, "call d2pc_pipeline_configure first");
+  if (!ctx->have_q) return fail(ctx, D2PC_ERR_NOT_CALIBRATED, "Q matrix not set");
+  const bool median = desc->median_ksize > 1;
+  if (median && (desc->dtype != D2PC_DTYPE_U8 || !median_ksize_supported(desc->median_ksize)))
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "median needs 8-bit input and an odd ksize in 3..11");
+  DeviceGuard guard(ctx->device);
+  Geom g;  // validates dtype / size / stride
+  int st = make_geom(ctx, desc->dtype, desc->scale, desc->width, desc->height, desc->row_stride_bytes, 0, 1, 0,
+                     ctx->cfg.mode == D2PC_MODE_COMPACT ? ctx->pxt_compact : ctx->pxt_parity, &g);
+  if (st != D2PC_OK) return st;
+  int found = -1;
+  for (int i = 0; i < ctx->pipe_depth; ++i)
+    if (ctx->slots[i].state == 0) {
+      found = i;
+      break;
+    }
+  if (found < 0)
+    return fail(ctx, D2PC_ERR_CAPACITY, "all %d pipeline slots are in use: collect and release one", ctx->pipe_depth);
+  PipeSlot &sl = ctx->slots[found];
+  const size_t in_bytes = size_t(desc->height) * desc->row_stride_bytes;
+  if ((st = grow_pinned(ctx, &sl.h_in, &sl.h_in_cap, in_bytes)) != D2PC_OK) return st;
+  if ((st = grow(ctx, &sl.d_in, &sl.d_in_cap, in_bytes)) != D2PC_OK) return st;
+  if (median && (st = grow(ctx, &sl.d_med, &sl.d_med_cap, in_bytes)) != D2PC_OK) return st;
+  sl.roi_n = g.roi_n;
+  sl.idx_off = (size_t(g.roi_n) * 16 + 255) & ~size_t(255);
+  const size_t out_bytes = sl.idx_off + (desc->want_index ? size_t(g.roi_n) * 4 : 0) + 256;
+  if ((st = grow_pinned(ctx, &sl.h_out, &sl.h_out_cap, out_bytes)) != D2PC_OK) return st;
+  if (!ctx->pipe_direct) {
+    if ((st = grow(ctx, &sl.d_out, &sl.d_out_cap, size_t(g.roi_n) * 16 + 16)) != D2PC_OK) return st;
+    if (desc->want_index && (st = grow(ctx, &sl.d_idx, &sl.d_idx_cap, size_t(g.roi_n) * 4 + 16)) != D2PC_OK) return st;
+  }
+  sl.desc = *desc;
+  sl.state = 1;
+  *host_in = sl.h_in;
+  *slot = found;
+  return D2PC_OK;
+}
+
+int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (slot < 0 || slot >= ctx->pipe_depth || ctx->slots[slot].state != 1)
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "slot %d was not acquired", slot);
+  DeviceGuard guard(ctx->device);
+  PipeSlot &sl = ctx->slots[slot];
+  const d2pc_frame_desc &d = sl.desc;
+  const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
+  Geom g;
+  int st = make_geom(ctx, d.dtype, d.scale, d.width, d.height, d.row_stride_bytes, 0, 1, 0,
+                     compact ? ctx->pxt_compact : ctx->pxt_parity, &g);
+  if (st != D2PC_OK) return st;
+  hipStream_t s = sl.stream;
+  const size_t in_bytes = size_t(d.height) * d.row_stride_bytes;
+  D2PC_HIP(ctx, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, s));
+  const void *kin = sl.d_in;
+  if (d.median_ksize > 1) {
+    MedianArgs m;
+    m.width = uint32_t(d.width);
+    m.height = uint32_t(d.height);
+    m.src_row_stride = m.dst_row_stride = uint32_t(d.row_stride_bytes);
+    D2PC_HIP(ctx, launch_median(sl.d_in, sl.d_med, m, d.median_ksize, s));
+    kin = sl.d_med;
+  }
+  sl.h_count[0] = 0;
+  if (g.roi_n) {
+    // direct mode: the kernels store points (and indices) straight into the
+    // pinned host buffer over PCIe; staged mode: into HBM, then one D2H copy
+    void *kout = ctx->pipe_direct ? sl.h_out : sl.d_out;
+    uint32_t *kidx = !d.want_index ? nullptr
+                     : ctx->pipe_direct ? reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(sl.h_out) + sl.idx_off)
+                                        : static_cast<uint32_t *>(sl.d_idx);
+    st = enqueue(ctx, g, kin, d.dtype, kout, kidx, sl.d_count, s, true, &sl.d_state, &sl.d_state_cap);
+    if (st != D2PC_OK) return st;
+    D2PC_HIP(ctx, hipMemcpyAsync(sl.h_count, sl.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (!ctx->pipe_direct) {
+      // COMPACT: the count is not known on the host yet, so the whole ROI
+      // capacity is copied; only the first h_count points are meaningful
+      D2PC_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, size_t(g.roi_n) * 16, hipMemcpyDeviceToHost, s));
+      if (d.want_index)
+        D2PC_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(sl.h_out) + sl.idx_off, sl.d_idx, size_t(g.roi_n) * 4,
+                                     hipMemcpyDeviceToHost, s));
+    }
+  }
+  D2PC_HIP(ctx, hipEventRecord(sl.done, s));
+  sl.seq = ++ctx->pipe_seq;
+  sl.state = 2;
+  return D2PC_OK;
+}
+
+int d2pc_pipeline_collect(d2pc_ctx *ctx, int *slot, const void **points, const uint32_t **index, size_t *n_points,
+                          uint64_t *tag) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!slot || !points || !n_points) return fail(ctx, D2PC_ERR_INVALID_ARG, "null argument");
+  int oldest = -1;
+  for (int i = 0; i < ctx->pipe_depth; ++i)
+    if (ctx->slots[i].state == 2 && (oldest < 0 || ctx->slots[i].seq < ctx->slots[oldest].seq)) oldest = i;
+  if (oldest < 0) return fail(ctx, D2PC_ERR_INVALID_ARG, "no submitted frame to collect");
+  DeviceGuard guard(ctx->device);
+  PipeSlot &sl = ctx->slots[oldest];
+  D2PC_HIP(ctx, hipEventSynchronize(sl.done));
+  if (ctx->cfg.mode == D2PC_MODE_COMPACT && ctx->cfg.compact_algo == 2 && sl.d_state) {
+    StateHeader h;
+    D2PC_HIP(ctx, hipMemcpy(&h, sl.d_state, sizeof h, hipMemcpyDeviceToHost));
+    if (h.timeout) return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
+  }
+  *slot = oldest;
+  *points = sl.h_out;
+  if (index)
+    *index = sl.desc.want_index ? reinterpret_cast<const uint32_t *>(static_cast<uint8_t *>(sl.h_out) + sl.idx_off)
+                                : nullptr;
+  *n_points = sl.roi_n ? sl.h_count[0] : 0;
+  if (tag) *tag = sl.desc.tag;
+  sl.state = 3;
+  return D2PC_OK;
+}
+
+int d2pc_pipeline_release(d2pc_ctx *ctx, int slot) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (slot < 0 || slot >= ctx->pipe_depth || (ctx->slots[slot].state != 3 && ctx->slots[slot].state != 1))
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "slot %d is not collected (or acquired)", slot);
+  ctx->slots[slot].state = 0;
   return D2PC_OK;
 }
 

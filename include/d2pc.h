@@ -191,6 +191,35 @@ int d2pc_process_mono8(d2pc_ctx *ctx, const uint8_t *image, int width, int heigh
                        void *out_points, uint32_t *out_index,
                        size_t capacity_points, size_t *n_points);
 
+/*
+ * Pipelined host path: up to `depth`
+ * frames in flight, each on its own HIP stream with its own PINNED staging:
+ *   acquire -> the caller decodes the image straight into pinned memory
+ *   submit  -> async H2D, (median), kernels, D2H (or, with direct_host_write,
+ *              the kernels store the points straight into pinned host memory)
+ *   collect -> waits for the OLDEST submitted frame and hands out a view of
+ *              its pinned output: the PointCloud2 payload without another copy
+ *   release -> the slot can be acquired again
+ * The copy in of frame i+1, the kernels of frame i and the copy out of frame
+ * i-1 overlap.  Frames are collected in submission order.
+ */
+typedef struct d2pc_frame_desc {
+  int32_t dtype;             /* d2pc_dtype */
+  float scale;               /* U8/U16 decode scale (cpp:61: 1/8) */
+  int32_t width, height;
+  size_t row_stride_bytes;   /* layout of the pinned input buffer */
+  int32_t median_ksize;      /* 0/1 = none; else odd 3..11, U8 only (cpp:55-57) */
+  int32_t want_index;        /* also produce source pixel indices */
+  uint64_t tag;              /* returned by collect (e.g. the message stamp) */
+} d2pc_frame_desc;
+
+int d2pc_pipeline_configure(d2pc_ctx *ctx, int depth /*1..8*/, int direct_host_write);
+int d2pc_pipeline_acquire(d2pc_ctx *ctx, const d2pc_frame_desc *desc, void **host_in, int *slot);
+int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot);
+int d2pc_pipeline_collect(d2pc_ctx *ctx, int *slot, const void **points, const uint32_t **index,
+                          size_t *n_points, uint64_t *tag);
+int d2pc_pipeline_release(d2pc_ctx *ctx, int slot);
+
 /* Pre-size the context's scratch (tile state, staging) for frames up to
  * width x height and batches up to n_frames. */
 int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames);

@@ -27,3 +27,36 @@ for (w, h) in ((640, 480), (752, 480), (1920, 1080), (3840, 2160)):
             dt = (time.perf_counter() - t0) / k
             print(f"{w}x{h} mode={'parity' if mode == 0 else 'compact'}: {dt*1e3:7.3f} ms/frame  {w*h/dt/1e6:8.1f} Mpix/s  "
                   f"({(w*h*4 + n.value*16)/dt/1e9:5.1f} GB/s over PCIe, {n.value} points)", flush=True)
+
+# pipelined path: depth-3 slots, pinned staging, frames submitted back to back
+for direct in (False, True):
+    for (w, h) in ((752, 480), (1920, 1080), (3840, 2160)):
+        for mode, kind in ((d2pc.MODE_PARITY, "uniform"), (d2pc.MODE_COMPACT, "holes")):
+            fr = synth_disparity(4, 0, w, h, kind)
+            with d2pc.Context(q=q, mode=mode) as ctx:
+                ctx.pipeline_configure(depth=3, direct_host_write=direct)
+                L = d2pc.load_library()
+                import ctypes
+                from disparity_to_point_cloud_amd.capi import FrameDesc
+                desc = FrameDesc(0, 1.0, w, h, w * 4, 0, 0, 0)
+                filled = set()
+                def submit():
+                    hin, slot = ctypes.c_void_p(), ctypes.c_int()
+                    assert L.d2pc_pipeline_acquire(ctx.handle, ctypes.byref(desc), ctypes.byref(hin), ctypes.byref(slot)) == 0
+                    if slot.value not in filled:  # the producer (decoder / camera driver) writes straight into pinned memory;
+                        ctypes.memmove(hin, fr.ctypes.data, fr.nbytes)  # its cost is not part of this path
+                        filled.add(slot.value)
+                    assert L.d2pc_pipeline_submit(ctx.handle, slot.value) == 0
+                def collect():
+                    slot, pts, n = ctypes.c_int(), ctypes.c_void_p(), ctypes.c_size_t()
+                    assert L.d2pc_pipeline_collect(ctx.handle, ctypes.byref(slot), ctypes.byref(pts), None, ctypes.byref(n), None) == 0
+                    L.d2pc_pipeline_release(ctx.handle, slot.value)
+                    return n.value
+                submit(); submit()
+                t0 = time.perf_counter(); k = 0
+                while time.perf_counter() - t0 < 1.0:
+                    submit(); npts = collect(); k += 1
+                dt = (time.perf_counter() - t0) / k
+                collect(); collect()
+                print(f"pipelined depth3 direct={int(direct)} {w}x{h} mode={'parity' if mode == 0 else 'compact'}: {dt*1e3:7.3f} ms/frame "
+                      f"{w*h/dt/1e6:8.1f} Mpix/s ({npts} points)", flush=True)
