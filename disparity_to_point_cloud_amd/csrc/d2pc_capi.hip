@@ -49,6 +49,7 @@ struct d2pc_ctx {
   // (fast and slow devices agree on 2048-pixel tiles and 2-4 tiles per block)
   int pxt_parity = 8, pxt_compact = 8;
   int blocks_per_cu = 128;
+  int onepass_blocks_per_cu = 3;
   int force_general_q = 0;
   int no_vec_rows = 0;
   // device scratch
@@ -216,6 +217,12 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   if (!d_counts) return fail(ctx, D2PC_ERR_INVALID_ARG, "COMPACT mode needs a d_counts buffer");
   a.pxt = ctx->pxt_compact;
   a.compact_algo = ctx->cfg.compact_algo == 2 ? 2 : 1;  // default: two-pass (faster today, no spin-waits)
+  if (a.compact_algo == 2) {
+    // the single-pass kernel is software-pipelined over a block's tiles: it
+    // wants few, long-lived blocks (about what is resident), not many short ones
+    const uint32_t persistent = uint32_t(ctx->cu_count) * uint32_t(ctx->onepass_blocks_per_cu);
+    a.grid = g.total_tiles < persistent ? g.total_tiles : persistent;
+  }
   a.state_bytes = compact_state_bytes(g);
   if (a.state_bytes > *state_cap) {
     if (!allow_alloc) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "compaction state not reserved (call d2pc_reserve)");
@@ -487,6 +494,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   if (!strcmp(key, "pxt_parity") && tile_shape_supported(value)) ctx->pxt_parity = value;
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
+  else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 1 && value <= 64) ctx->onepass_blocks_per_cu = value;
   else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
@@ -529,7 +537,8 @@ int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scal
 
 int d2pc_check_async_error(d2pc_ctx *ctx) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
-  if (!ctx->d_state) return D2PC_OK;
+  // only the single-pass algorithm has bounded spins (and zeroes the header)
+  if (!ctx->d_state || ctx->cfg.compact_algo != 2) return D2PC_OK;
   DeviceGuard guard(ctx->device);
   StateHeader h;
   D2PC_HIP(ctx, hipMemcpy(&h, ctx->d_state, sizeof h, hipMemcpyDeviceToHost));

@@ -78,7 +78,7 @@ enum : int { QK_GENERAL = 0, QK_STEREO = 1 };
 // ---- compaction state (zeroed by a memset node before every launch) -------
 //   [StateHeader 64 B][frame 0 state][frame 1 state]...
 //   frame state (frame_state_stride bytes, 256-B aligned):
-//     [ticket u32 on its own 64-B line][group_acc u64 x groups][16 B x tiles]
+//     [ticket u32 alone in 256 B][group_acc u64, one per 128-B line][16 B x tiles]
 //   the 16 B per tile hold one u64 granule (single pass) or 4 x u32 wave counts (two-pass)
 //   group_acc = (tiles arrived << 32) | sum of their point counts
 //   granule   = kGranuleTag | point count of one tile
@@ -88,7 +88,8 @@ struct StateHeader {
   // diagnostic build only (-DD2PC_DIAG): shader-clock sums over all tiles
   unsigned long long diag[7];  // tiles, spins, t_compute, t_ticket, t_wait, t_scatter, t_total
 };
-constexpr uint32_t kFrameTicketBytes = 64;
+constexpr uint32_t kFrameTicketBytes = 256;   // the ticket word has a 256-B block to itself
+constexpr uint32_t kGroupAccStride = 128;     // one group accumulator per 128-B line
 constexpr uint64_t kGranuleTag = uint64_t(1) << 63;
 constexpr int kGroupTiles = 64;         // tiles per counting group
 constexpr uint32_t kSpinLimit = 1u << 20;

@@ -201,7 +201,22 @@ struct TileIn {
   uint32_t uu[PXT], vv[PXT];  // image coordinates (border added)
 };
 
-// Loads are issued first (all in flight), arithmetic comes later.
+// Image coordinates of the thread's PXT pixels (see slot_pixel).
+template <int PXT>
+__device__ __forceinline__ void tile_coords(uint32_t (&uu)[PXT], uint32_t (&vv)[PXT], const Geom &g, uint32_t base,
+                                            uint32_t wave, uint32_t lane) {
+  Walker w(g, base + wave * 256u + lane);
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    uu[k] = w.u + g.border;
+    vv[k] = w.v + g.border;
+    if ((k & 3) == 3) w.step(g, g.s832_v, g.s832_u);  // to slot 0 of the next batch
+    else w.step(g, g.s64_v, g.s64_u);
+  }
+}
+
+// Disparities of the thread's PXT pixels; loads are issued first (all in
+// flight), arithmetic comes later.
 //  VEC = false: one dword per lane and slot (any dtype, any alignment).
 //  VEC = true : fp32 rows whose 4-pixel groups are 16-B aligned and never
 //               straddle a ROI row (host-checked): one 16-B load per lane and
@@ -209,24 +224,18 @@ struct TileIn {
 //               slot layout through the wave's own LDS strip.  LDS is in-order
 //               per wave, so no barrier is involved.
 template <int DT, int PXT, bool VEC>
-__device__ __forceinline__ void tile_load(TileIn<PXT> &t, const uint8_t *fin, const Geom &g, uint32_t base,
-                                          uint32_t wave, uint32_t lane, float *wave_strip) {
-  Walker w(g, base + wave * 256u + lane);
-#pragma unroll
-  for (int k = 0; k < PXT; ++k) {
-    t.uu[k] = w.u + g.border;
-    t.vv[k] = w.v + g.border;
-    if ((k & 3) == 3) w.step(g, g.s832_v, g.s832_u);  // to slot 0 of the next batch
-    else w.step(g, g.s64_v, g.s64_u);
-  }
+__device__ __forceinline__ void tile_load_d(float (&d)[PXT], const uint8_t *fin, const Geom &g, uint32_t base,
+                                            uint32_t wave, uint32_t lane, float *wave_strip) {
   if constexpr (!VEC) {
+    uint32_t uu[PXT], vv[PXT];
+    tile_coords<PXT>(uu, vv, g, base, wave, lane);
 #pragma unroll
     for (int k = 0; k < PXT; ++k) {
       // byte offsets grow with the ROI index, so clamping to the last ROI
       // pixel keeps the tail slots of a frame's last tile in bounds without
       // predicating the loads (their results are never stored)
-      const uint32_t off = t.vv[k] * g.row_stride + t.uu[k] * elem_bytes<DT>();
-      t.d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
+      const uint32_t off = vv[k] * g.row_stride + uu[k] * elem_bytes<DT>();
+      d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
     }
   } else {
     static_assert(!VEC || DT == DT_F32, "16-B row loads are fp32 only");
@@ -245,11 +254,18 @@ __device__ __forceinline__ void tile_load(TileIn<PXT> &t, const uint8_t *fin, co
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int sl = 0; sl < 4; ++sl) t.d[j * 4 + sl] = wave_strip[uint32_t(sl) * 64u + lane];
+      for (int sl = 0; sl < 4; ++sl) d[j * 4 + sl] = wave_strip[uint32_t(sl) * 64u + lane];
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   }
+}
+
+template <int DT, int PXT, bool VEC>
+__device__ __forceinline__ void tile_load(TileIn<PXT> &t, const uint8_t *fin, const Geom &g, uint32_t base,
+                                          uint32_t wave, uint32_t lane, float *wave_strip) {
+  tile_coords<PXT>(t.uu, t.vv, g, base, wave, lane);
+  tile_load_d<DT, PXT, VEC>(t.d, fin, g, base, wave, lane, wave_strip);
 }
 
 template <int DT, int QK, int PXT>
@@ -363,11 +379,16 @@ struct FrameState {
     uint8_t *fs = state + sizeof(StateHeader) + uint64_t(f) * g.frame_state_stride;
     ticket = reinterpret_cast<uint32_t *>(fs);
     group_acc = reinterpret_cast<uint64_t *>(fs + kFrameTicketBytes);
-    granules = group_acc + g.groups_per_frame;
+    granules = reinterpret_cast<uint64_t *>(fs + kFrameTicketBytes + uint64_t(g.groups_per_frame) * kGroupAccStride);
   }
   // two-pass view of the granule area: 4 x uint32 per tile (per-wave counts,
   // then the tile's exclusive prefix in word 0)
   __device__ __forceinline__ uint32_t *partials() const { return reinterpret_cast<uint32_t *>(granules); }
+  // every group accumulator sits on a line of its own: each is hit by 64
+  // atomics and by the polls of every later tile of the frame
+  __device__ __forceinline__ uint64_t *group_word(uint32_t grp) const {
+    return reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(group_acc) + uint64_t(grp) * kGroupAccStride);
+  }
 };
 
 __device__ __forceinline__ void backoff(uint32_t spins) {
@@ -414,26 +435,38 @@ __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, Sta
 // lt: complete groups via the group accumulators, the own (partial) group via
 // tile granules.  WAIT = true (single pass): bounded wait until every
 // predecessor has published; WAIT = false (two-pass): values are final.
+// What a block already knows about its frame: groups [0, groups) are complete
+// and their counts add up to `sum`.  A block's successive tiles are less than
+// a group apart, so each prefix needs ~one new group word, not all of them.
+struct KnownGroups {
+  uint32_t groups = 0, sum = 0;
+};
+
 template <bool WAIT>
 __device__ __forceinline__ uint32_t prefix_before(const FrameState &fs, StateHeader *hdr, uint32_t lt,
-                                                  uint32_t lane, uint32_t &spin_acc) {
+                                                  uint32_t lane, uint32_t &spin_acc, KnownGroups &known) {
   const uint32_t grp = lt / kGroupTiles;
   uint32_t sum = 0;
-  for (uint32_t g0 = 0; g0 < grp; g0 += 64) {  // groups 0..grp-1 hold kGroupTiles tiles each
+  for (uint32_t g0 = known.groups; g0 < grp; g0 += 64) {  // groups below grp hold kGroupTiles tiles each
     const uint32_t gi = g0 + lane;
     const bool on = gi < grp;
-    const uint64_t v = read_counted<WAIT>(fs.group_acc + gi, on, hdr, lane, spin_acc,
+    const uint64_t v = read_counted<WAIT>(fs.group_word(gi), on, hdr, lane, spin_acc,
                                           [](uint64_t x) { return uint32_t(x >> 32) == uint32_t(kGroupTiles); });
     sum += on ? uint32_t(v) : 0u;
   }
+  if (grp > known.groups) {  // wave-uniform
+    known.sum += wave_sum(sum);
+    known.groups = grp;
+  }
+  sum = 0;
   {  // tiles grp*64 .. lt-1 of the own group (< 64 of them)
     const uint32_t ti = grp * kGroupTiles + lane;
     const bool on = ti < lt;
-    const uint64_t v = read_counted<WAIT>(fs.granules + ti, on, hdr, lane, spin_acc,
+    const uint64_t v = read_counted<WAIT>(fs.granules + 2u * ti, on, hdr, lane, spin_acc,
                                           [](uint64_t x) { return (x & kGranuleTag) != 0; });
     sum += on ? uint32_t(v) : 0u;
   }
-  return wave_sum(sum);
+  return known.sum + wave_sum(sum);
 }
 
 template <int DT, int QK, int PXT>
@@ -597,35 +630,62 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
 }
 
 // --------------------------------------------------------------------------
-// K2: single-pass compaction.
-//  * A block serves ONE frame at a time (frame = blockIdx % n_frames), and
+// K2: single-pass compaction (each disparity is read once).
+//  * A block serves ONE frame at a time (frame = blockIdx % n_frames) and
 //    takes that frame's tiles from the frame's own ticket counter: every
-//    predecessor of a tile is therefore already running (or done) when the
-//    tile starts, so waiting for predecessors' COUNTS cannot deadlock
-//    whatever the dispatch order or residency.  Per-frame counters keep the
-//    ticket atomics, and the words the waiters poll, spread over addresses.
-//  * A tile publishes its count right after its own loads (it never waits
-//    before publishing), so there is no serial chain: the wait is for the
-//    slowest predecessor's load, not for a scan to ripple through.
+//    predecessor of a tile is already running (or done) when the tile starts,
+//    so waiting for predecessors' COUNTS cannot deadlock whatever the
+//    dispatch order or residency.
+//  * A tile publishes its count as soon as it is known and only needs the
+//    counts of its predecessors -- no scan ripples through the frame.
+//  * 5 waves per block: four WORKER waves stream pixels; one CONTROL wave
+//    owns the protocol (ticket atomics, publishing, polling), so the workers
+//    never sit behind an atomic's round trip.
+//  * Software pipeline over a block's tiles, holding only DISPARITIES in
+//    registers: iteration i COUNTS tile t (exact validity predicate, a few
+//    operations per pixel for a stereoRectify-structured Q), the control wave
+//    publishes t, fetches the ticket of t+1 and waits for the prefix of t-1
+//    (published an iteration ago, so normally ready at the first look); then
+//    t+1's loads are issued and tile t-1 is reprojected and scattered.
 // --------------------------------------------------------------------------
+constexpr uint32_t kNoTile = 0xffffffffu;
+
+template <int QK, int PXT>
+__device__ __forceinline__ void tile_validity(const QArg<QK> &Q, const Geom &g, const float (&d)[PXT], uint32_t base,
+                                              uint32_t wave, uint32_t lane, uint64_t (&mask)[PXT]) {
+  uint32_t uu[PXT], vv[PXT];
+  tile_coords<PXT>(uu, vv, g, base, wave, lane);
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    const uint32_t i = slot_pixel(base, wave, lane, k);
+    bool ok;
+    if constexpr (QK == QK_STEREO) {
+      ok = stereo_point_valid(Q, uu[k], vv[k], d[k], g.min_disparity);
+    } else {
+      float X, Y, Z;
+      reproject(Q, uu[k], vv[k], d[k], X, Y, Z);
+      ok = point_is_valid(X, Y, Z, d[k], g.min_disparity);
+    }
+    mask[k] = __ballot(ok && i < g.roi_n);
+  }
+}
+
 template <int DT, int QK, int PXT, bool VEC>
-__global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__restrict__ disp,
-                                                            float4 *__restrict__ out,
-                                                            uint32_t *__restrict__ out_index,
-                                                            uint32_t *__restrict__ counts, uint8_t *state,
-                                                            const Geom g, const QArg<QK> Q) {
+__global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *__restrict__ disp,
+                                                                 float4 *__restrict__ out,
+                                                                 uint32_t *__restrict__ out_index,
+                                                                 uint32_t *__restrict__ counts, uint8_t *state,
+                                                                 const Geom g, const QArg<QK> Q) {
   using gu64 = __attribute__((address_space(1))) uint64_t;
   constexpr int CELLS = PXT * (kBlock / 64);
   __shared__ uint32_t s_cnt[CELLS];
-  __shared__ uint32_t s_prefix;
-  __shared__ uint32_t s_ticket[2];
+  __shared__ uint32_t s_excl[2][CELLS];  // per-cell exclusive offsets of the tile counted in iteration it
+  __shared__ uint32_t s_total[2], s_next[2], s_prefix[2];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  D2PC_DECLARE_STRIPS(VEC, wave);
+  const bool ctl = wave == kBlock / 64;  // the fifth wave
+  D2PC_DECLARE_STRIPS(VEC, wave < kBlock / 64 ? wave : 0u);
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
   uint32_t spin_acc = 0;
-#ifdef D2PC_DIAG
-  unsigned long long dg[6] = {0, 0, 0, 0, 0, 0};
-#endif
 
   for (uint32_t f = blockIdx.x % g.n_frames; f < g.n_frames; f += gridDim.x) {
     const FrameState fs(state, g, f);
@@ -633,77 +693,106 @@ __global__ __launch_bounds__(kBlock) void k_compact_onepass(const uint8_t *__res
     float4 *fout = out + uint64_t(f) * g.out_frame_stride;
     uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
 
-    if (tid == 0) s_ticket[0] = atomicAdd(fs.ticket, 1u);
+    if (ctl && lane == 0) s_next[1] = atomicAdd(fs.ticket, 1u);
     __syncthreads();
-    uint32_t lt = s_ticket[0];
-    uint32_t it = 0;
-    while (lt < g.tiles_per_frame) {
-#ifdef D2PC_DIAG
-      const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-      unsigned long long c1 = 0, c2 = 0, c3 = 0;
-#endif
-      const uint32_t base = lt * uint32_t(kBlock * PXT);
-      TileRegs<DT, QK, PXT> r;
-      uint64_t mask[PXT];
-      tile_compute<DT, QK, PXT, VEC>(r, fin, g, Q, base, wave, lane, wave_strip);
-      tile_ballots<DT, QK, PXT>(r, g, base, wave, lane, mask);
-      if (lane == 0) {
+    uint32_t cur = s_next[1];
+    if (cur >= g.tiles_per_frame) cur = kNoTile;
+    uint32_t prev = kNoTile;
+    KnownGroups known;  // control wave: prefix of the frame's complete groups seen so far
+
+    float dc[PXT];  // tile `cur`: disparities (loads in flight until the count phase)
+    float dp[PXT];  // tile `prev`: disparities, counted and published, waiting for its prefix
+    uint64_t pmask[PXT];
+    uint32_t pexcl[PXT];
+    uint32_t ptotal = 0;
 #pragma unroll
-        for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = uint32_t(__popcll(mask[k]));
+    for (int k = 0; k < PXT; ++k) {
+      dc[k] = dp[k] = 0.f;
+      pmask[k] = 0;
+      pexcl[k] = 0;
+    }
+    if (!ctl && cur != kNoTile)
+      tile_load_d<DT, PXT, VEC>(dc, fin, g, cur * uint32_t(kBlock * PXT), wave, lane, wave_strip);
+
+    for (uint32_t it = 0; cur != kNoTile || prev != kNoTile; ++it) {
+      const uint32_t slot = it & 1u;
+      uint64_t mask[PXT];
+      if (ctl) {
+        // ticket of the tile after `cur`, and the prefix of `prev`
+        if (cur != kNoTile && lane == 0) s_next[slot] = atomicAdd(fs.ticket, 1u);
+        if (prev != kNoTile) {
+          const uint32_t p = prefix_before<true>(fs, hdr, prev, lane, spin_acc, known);
+          if (lane == 0) s_prefix[slot] = p;
+        }
+      } else if (cur != kNoTile) {
+        tile_validity<QK, PXT>(Q, g, dc, cur * uint32_t(kBlock * PXT), wave, lane, mask);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = uint32_t(__popcll(mask[k]));
+        }
       }
       __syncthreads();
-      uint32_t total;
-      const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
-      if (wave == 0) {
-        uint32_t next_lt = 0;
+      if (ctl && cur != kNoTile) {
+        uint32_t total;
+        const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
+        if (lane < uint32_t(CELLS)) s_excl[slot][lane] = excl;
         if (lane == 0) {
+          s_total[slot] = total;
           // publish: tagged granule (the data is the flag) + group accumulator
-          __hip_atomic_store((gu64 *)(fs.granules + lt), kGranuleTag | total, __ATOMIC_RELAXED,
+          __hip_atomic_store((gu64 *)(fs.granules + 2u * cur), kGranuleTag | total, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_fetch_add((gu64 *)(fs.group_acc + lt / kGroupTiles), (uint64_t(1) << 32) | total,
+          __hip_atomic_fetch_add((gu64 *)fs.group_word(cur / kGroupTiles), (uint64_t(1) << 32) | total,
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // Take the next ticket only NOW, after publishing: a ticket held
-          // while its tile is not yet loading delays every later tile of the
-          // frame (they wait for its count), which locks the blocks in step.
-#ifdef D2PC_DIAG
-          c1 = __builtin_amdgcn_s_memtime();
-#endif
-          next_lt = atomicAdd(fs.ticket, 1u);
-#ifdef D2PC_DIAG
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          c2 = __builtin_amdgcn_s_memtime();
-#endif
-        }
-        const uint32_t p = prefix_before<true>(fs, hdr, lt, lane, spin_acc);
-#ifdef D2PC_DIAG
-        c3 = __builtin_amdgcn_s_memtime();
-#endif
-        if (lane == 0) {
-          s_prefix = p;
-          s_ticket[(it + 1) & 1] = next_lt;
         }
       }
       __syncthreads();
-      const uint32_t prefix = s_prefix;
-      tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane, g.roi_n);
-      if (counts && lt == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + total;
-#ifdef D2PC_DIAG
-      if (tid == 0) {
-        const unsigned long long c4 = __builtin_amdgcn_s_memtime();
-        dg[0] += 1; dg[1] += c1 - c0; dg[2] += c2 - c1; dg[3] += c3 - c2; dg[4] += c4 - c3; dg[5] += c4 - c0;
+      uint32_t next = kNoTile;
+      if (cur != kNoTile) {
+        next = s_next[slot];
+        if (next >= g.tiles_per_frame) next = kNoTile;
       }
-#endif
-      lt = s_ticket[(it + 1) & 1];
-      ++it;
+      if (!ctl) {
+        // loads of the next tile first: they fly while `prev` is reprojected and scattered
+        float dn[PXT];
+#pragma unroll
+        for (int k = 0; k < PXT; ++k) dn[k] = 0.f;
+        if (next != kNoTile)
+          tile_load_d<DT, PXT, VEC>(dn, fin, g, next * uint32_t(kBlock * PXT), wave, lane, wave_strip);
+        if (prev != kNoTile) {
+          const uint32_t prefix = s_prefix[slot];
+          uint32_t uu[PXT], vv[PXT];
+          tile_coords<PXT>(uu, vv, g, prev * uint32_t(kBlock * PXT), wave, lane);
+#pragma unroll
+          for (int k = 0; k < PXT; ++k) {
+            float X, Y, Z;
+            reproject(Q, uu[k], vv[k], dp[k], X, Y, Z);
+            const uint32_t pos = prefix + pexcl[k] + mbcnt64(pmask[k]);
+            if (((pmask[k] >> lane) & 1) && pos < g.roi_n) {
+              store_point(fout, pos, X, Y, Z);
+              if (fidx) store_index(fidx, pos, vv[k] * g.width + uu[k]);
+            }
+          }
+          if (counts && prev == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + ptotal;
+        }
+        if (cur != kNoTile) {
+          ptotal = s_total[slot];
+#pragma unroll
+          for (int k = 0; k < PXT; ++k) {
+            dp[k] = dc[k];
+            pmask[k] = mask[k];
+            pexcl[k] = s_excl[slot][cell_index(k, wave)];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < PXT; ++k) dc[k] = dn[k];
+      }
+      prev = cur;
+      cur = next;
     }
     __syncthreads();
   }
 #ifdef D2PC_DIAG
-  if (tid == 0) {  // one flush per block
-    atomicAdd(&hdr->diag[0], dg[0]);
-    atomicAdd(&hdr->diag[1], (unsigned long long)spin_acc);
-    for (int j = 1; j < 6; ++j) atomicAdd(&hdr->diag[j + 1], dg[j]);
-  }
+  if (ctl && lane == 0) atomicAdd(&hdr->diag[1], (unsigned long long)spin_acc);
 #endif
 }
 
@@ -750,7 +839,7 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
     // frame-static assignment: the grid is a multiple of n_frames, or smaller
     uint32_t grid = a.grid;
     if (grid >= a.geom.n_frames) grid -= grid % a.geom.n_frames;
-    hipLaunchKernelGGL((k_compact_onepass<DT, QK, PXT, VEC>), dim3(grid), dim3(kBlock), 0, a.stream, disp, out,
+    hipLaunchKernelGGL((k_compact_onepass<DT, QK, PXT, VEC>), dim3(grid), dim3(kBlock + 64), 0, a.stream, disp, out,
                        a.out_index, a.counts, state, a.geom, make_qarg<QK>(a));
   }
   return hipGetLastError();
@@ -778,7 +867,7 @@ bool tile_shape_supported(int pxt) { return pxt == 4 || pxt == 8 || pxt == 16; }
 
 uint32_t frame_state_stride(uint32_t tiles_per_frame) {
   const uint32_t groups = (tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
-  const uint64_t b = kFrameTicketBytes + uint64_t(groups) * 8 + uint64_t(tiles_per_frame) * 16;
+  const uint64_t b = kFrameTicketBytes + uint64_t(groups) * kGroupAccStride + uint64_t(tiles_per_frame) * 16;
   return uint32_t((b + 255) & ~uint64_t(255));
 }
 

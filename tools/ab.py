@@ -63,6 +63,8 @@ def main():
             ctx = capi.Context(q=capi.make_q(), border=int(border), mode=m, compact_algo=int(algo))
             ctx.set_tuning("pxt_parity", int(pxt)); ctx.set_tuning("pxt_compact", int(pxt))
             ctx.set_tuning("blocks_per_cu", int(bpc)); ctx.set_tuning("no_vec_rows", int(nv))
+            if int(algo) == 2:
+                ctx.set_tuning("onepass_blocks_per_cu", min(int(bpc), 64))
             b = Cand(ctx)
             b.launch(); torch.cuda.synchronize()
             npts = int(counts.sum().item())
