@@ -138,7 +138,9 @@ __device__ __forceinline__ void store_point(float4 *frame_out, uint32_t point, f
 }
 
 __device__ __forceinline__ void store_index(uint32_t *frame_idx, uint32_t point, uint32_t pix) {
-  st(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(frame_idx) + (point << 2)), pix);
+  // plain store: a wave writes only 256 B of indices (partial lines that L2 must merge with its
+  // neighbours' pieces); nt here cost +20 % on the 30 %-holes + index case
+  *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(frame_idx) + (point << 2)) = pix;
 }
 
 // Exact validity of a STEREO-structured point WITHOUT evaluating it (used by
