@@ -23,14 +23,18 @@ def init_distributed(backend=None):
     """Initialise torch.distributed from the torchrun environment (no-op for a
     single process).  Returns (rank, local_rank, world_size)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    # D2PC_FORCE_DIST=1 initialises the group even for one rank (exercises RCCL on a 1-GPU box)
+    if (world > 1 or os.environ.get("D2PC_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
@@ -43,7 +47,7 @@ def _comm_device():
 def broadcast_blob(blob, src=0) -> bytes:
     """Broadcast the calibration blob from `src`; every rank returns the bytes."""
     n = capi.CALIB_BLOB_BYTES
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         assert blob is not None and len(blob) == n
         return bytes(blob)
     dev = _comm_device()
@@ -74,7 +78,7 @@ def shard_frames(n_frames_total: int, rank: int, world: int):
 
 
 def allreduce_max(x: float) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(x)
     t = torch.tensor([x], dtype=torch.float64, device=_comm_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -84,11 +88,11 @@ def allreduce_max(x: float) -> float:
 def allreduce_sum_counters(counters) -> np.ndarray:
     """Sum of per-rank {frames, pixels, points, ns} style counters."""
     t = torch.tensor(list(counters), dtype=torch.int64, device=_comm_device())
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
