@@ -45,6 +45,26 @@ def test_prep_mono8_and_mono16_match_oracle(replay, tmp_path):
     assert np.array_equal(got, oracle.median_u8(oracle.mono16_to_mono8(img16), 11))
 
 
+def test_host_plumbing_under_asan_ubsan(tmp_path):
+    """sanitizers on the CPU build of the host code
+    (GPU sanitizers are not available on this pool)."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "host"), "sanitize"], check=True, capture_output=True)
+    asan = os.path.join(ROOT, "host", "d2pc_replay_asan")
+    rng = np.random.default_rng(23)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    for enc, img in (("mono8", rng.integers(0, 256, size=(37, 41)).astype(np.uint8)),
+                     ("mono16", rng.integers(0, 65536, size=(12, 5)).astype(np.uint16)),
+                     ("mono8", rng.integers(0, 256, size=(1, 1)).astype(np.uint8))):
+        src, dst = tmp_path / "in.raw", tmp_path / "out.raw"
+        src.write_bytes(img.tobytes())
+        p = subprocess.run([asan, "prep", str(src), str(img.shape[1]), str(img.shape[0]), enc, str(dst)],
+                           capture_output=True, text=True, timeout=120, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        want = img if enc == "mono8" else oracle.mono16_to_mono8(img)
+        got = np.frombuffer(dst.read_bytes(), dtype=np.uint8).reshape(img.shape)
+        assert np.array_equal(got, oracle.median_u8(want, 11))
+
+
 def test_non_colour_encoding_is_rejected_like_cv_bridge(replay, tmp_path):
     img = np.ones((8, 8), dtype=np.float32)
     p, _ = _run(replay, "prep", img, "32FC1", tmp_path)
