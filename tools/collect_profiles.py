@@ -52,6 +52,12 @@ for (k, c), v in cal_w.items():
 if fetch_factor is None:
     fetch_factor = 2.0
 fetch, write = counters(f"{tag}_fetch"), counters(f"{tag}_write")
+for extra in (f"{tag}_cfetch", f"{tag}_cwrite"):  # the same passes with bench.py --mode compact
+    for k, v in counters(extra).items():
+        (fetch if k[1] == "FETCH_SIZE" else write).setdefault(k, []).extend(v)
+sq = counters(f"{tag}_sq")
+if sq:
+    summary["sq_counters_parity_kernel"] = {c: sum(v) / len(v) for (k, c), v in sq.items() if "k_reproject_pack" in k}
 per_kernel = collections.defaultdict(dict)
 for (k, c), v in list(fetch.items()) + list(write.items()):
     if "d2pc::" in k:
@@ -80,6 +86,16 @@ if main:
         "hbm_bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb,
         "source": f"profiles/{rnd}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                   f"FETCH_SIZE x{round(fetch_factor,3)} per calibration)"}
+    cf = one(f"{tag}_cfetch/*/*_counter_collection.csv"); cw = one(f"{tag}_cwrite/*/*_counter_collection.csv")
+    if cf and cw:
+        def mean_of(path, ctr, kern):
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kern in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            return sum(vals) / len(vals) if vals else 0.0
+        rb = sum(mean_of(cf, "FETCH_SIZE", k) for k in ("k_compact_count", "k_compact_scan", "k_compact_scatter")) * 1024 * round(fetch_factor, 3)
+        wb = sum(mean_of(cw, "WRITE_SIZE", k) for k in ("k_compact_count", "k_compact_scan", "k_compact_scatter")) * 1024
+        traffic["compact_border40_frames16"] = {
+            "hbm_bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb,
+            "source": f"profiles/{rnd}_pmc_summary.json (count + scan + scatter kernels; the count pass reads the input a second time)"}
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
 print(json.dumps(traffic, indent=1))
