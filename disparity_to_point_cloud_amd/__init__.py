@@ -23,6 +23,7 @@ from .capi import (  # noqa: F401
     library_path,
     load_library,
     make_q,
+    make_q_disparity_image,
     roi_points,
     status_string,
 )

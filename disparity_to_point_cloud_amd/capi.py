@@ -18,7 +18,7 @@ CALIB_BLOB_BYTES = 136
 # every symbol include/d2pc.h declares (tests check the library exports all)
 ABI_SYMBOLS = [
     "d2pc_abi_version", "d2pc_status_string", "d2pc_device_count", "d2pc_make_q", "d2pc_config_init",
-    "d2pc_calib_pack", "d2pc_calib_unpack",
+    "d2pc_calib_pack", "d2pc_calib_unpack", "d2pc_make_q_disparity_image", "d2pc_set_min_disparity",
     "d2pc_create", "d2pc_destroy", "d2pc_last_error", "d2pc_set_q", "d2pc_get_q", "d2pc_set_border",
     "d2pc_set_mode", "d2pc_get_config", "d2pc_export_calibration", "d2pc_import_calibration",
     "d2pc_roi_points", "d2pc_cloud_meta_fill", "d2pc_process", "d2pc_process_device", "d2pc_reserve",
@@ -98,6 +98,8 @@ def load_library():
     L.d2pc_status_string.restype = cp
     L.d2pc_device_count.restype = ctypes.c_int
     L.d2pc_make_q.argtypes = [ctypes.c_double] * 5 + [ctypes.c_int, ctypes.c_int, dp]
+    L.d2pc_make_q_disparity_image.argtypes = [ctypes.c_double] * 4 + [dp]
+    L.d2pc_set_min_disparity.argtypes = [vp, ctypes.c_float]
     L.d2pc_calib_pack.argtypes = [dp, ctypes.c_int, ctypes.c_int, vp]
     L.d2pc_calib_unpack.argtypes = [vp, ctypes.c_size_t, dp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.d2pc_config_init.argtypes = [ctypes.POINTER(Config)]
@@ -167,6 +169,15 @@ def make_q(fx=714.24, fy=713.5, cx=376.0, cy=240.0, baseline=0.09, nx=752, ny=48
                                     q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     if st:
         raise D2pcError(st, "d2pc_make_q")
+    return q
+
+
+def make_q_disparity_image(f, T, cx, cy) -> np.ndarray:
+    """Q for a stereo_msgs/DisparityImage-style source: Z = f*T/d."""
+    q = np.zeros(16, dtype=np.float64)
+    st = load_library().d2pc_make_q_disparity_image(f, T, cx, cy, q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    if st:
+        raise D2pcError(st, "d2pc_make_q_disparity_image")
     return q
 
 
@@ -256,6 +267,9 @@ class Context:
 
     def set_mode(self, mode: int):
         self._check(self._L.d2pc_set_mode(self._h, mode))
+
+    def set_min_disparity(self, min_disparity: float):
+        self._check(self._L.d2pc_set_min_disparity(self._h, min_disparity))
 
     def config(self) -> Config:
         cfg = Config()

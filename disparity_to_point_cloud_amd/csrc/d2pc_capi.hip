@@ -306,6 +306,16 @@ int d2pc_make_q(double fx, double fy, double cx, double cy, double baseline, int
   return D2PC_OK;
 }
 
+int d2pc_make_q_disparity_image(double f, double T, double cx, double cy, double q[16]) {
+  if (!q || !(f > 0) || !(T > 0) || !std::isfinite(cx) || !std::isfinite(cy)) return D2PC_ERR_INVALID_ARG;
+  for (int i = 0; i < 16; ++i) q[i] = 0.0;
+  q[0] = 1.0;  q[3] = -cx;
+  q[5] = 1.0;  q[7] = -cy;
+  q[11] = f;
+  q[14] = 1.0 / T;
+  return D2PC_OK;
+}
+
 int d2pc_config_init(d2pc_config *cfg) {
   if (!cfg) return D2PC_ERR_INVALID_ARG;
   memset(cfg, 0, sizeof *cfg);
@@ -409,6 +419,13 @@ int d2pc_set_mode(d2pc_ctx *ctx, int mode) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
   if (mode != D2PC_MODE_PARITY && mode != D2PC_MODE_COMPACT) return fail(ctx, D2PC_ERR_INVALID_ARG, "bad mode %d", mode);
   ctx->cfg.mode = mode;
+  return D2PC_OK;
+}
+
+int d2pc_set_min_disparity(d2pc_ctx *ctx, float min_disparity) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (std::isnan(min_disparity)) return fail(ctx, D2PC_ERR_INVALID_ARG, "min_disparity is NaN");
+  ctx->cfg.min_disparity = min_disparity;
   return D2PC_OK;
 }
 

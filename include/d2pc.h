@@ -106,6 +106,12 @@ int d2pc_device_count(void);            /* number of HIP devices, 0 if none  */
 int d2pc_make_q(double fx, double fy, double cx, double cy, double baseline,
                 int nx, int ny, double q_out[16]);
 
+/* Q for a stereo_msgs/DisparityImage-style source (SURVEY.md section 8(f) #3:
+ * calibration carried by the message instead of ~fx_.. parameters): focal
+ * length f (pixels), baseline T (metres, > 0), principal point (cx, cy):
+ *   Q = [1 0 0 -cx; 0 1 0 -cy; 0 0 0 f; 0 0 1/T 0]  =>  Z = f*T/d. */
+int d2pc_make_q_disparity_image(double f, double T, double cx, double cy, double q_out[16]);
+
 /* Host-only packing of the calibration blob (what rank 0 broadcasts): usable
  * without a device, e.g. by the process that owns the ROS parameters. */
 int d2pc_calib_pack(const double q[16], int border, int mode, void *blob /*136 B*/);
@@ -122,6 +128,9 @@ int d2pc_set_q(d2pc_ctx *ctx, const double q[16]);
 int d2pc_get_q(const d2pc_ctx *ctx, double q_out[16]);
 int d2pc_set_border(d2pc_ctx *ctx, int border);
 int d2pc_set_mode(d2pc_ctx *ctx, int mode);
+/* COMPACT predicate threshold (e.g. DisparityImage.min_disparity): points with
+ * d <= min_disparity are dropped; -inf disables it.  NaN is rejected. */
+int d2pc_set_min_disparity(d2pc_ctx *ctx, float min_disparity);
 int d2pc_get_config(const d2pc_ctx *ctx, d2pc_config *cfg_out);
 int d2pc_export_calibration(const d2pc_ctx *ctx, void *blob /*136 B*/);
 int d2pc_import_calibration(d2pc_ctx *ctx, const void *blob, size_t blob_bytes);

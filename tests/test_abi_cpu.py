@@ -135,3 +135,16 @@ def test_fastdiv_reference_model():
         t = (ns * np.uint64(m)) >> np.uint64(32)
         q = ((t + ((ns - t) >> np.uint64(s1))) & np.uint64(0xFFFFFFFF)) >> np.uint64(s2)
         assert np.array_equal(q, ns // np.uint64(d)), d
+
+
+def test_make_q_disparity_image():
+    q = d2pc.make_q_disparity_image(700.0, 0.12, 320.5, 240.25)
+    want = np.zeros(16)
+    want[[0, 5]] = 1
+    want[3], want[7], want[11], want[14] = -320.5, -240.25, 700.0, 1 / 0.12
+    assert np.array_equal(q, want)
+    lib = d2pc.load_library()
+    qp = q.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert lib.d2pc_make_q_disparity_image(0.0, 0.1, 1.0, 1.0, qp) == 1
+    assert lib.d2pc_make_q_disparity_image(1.0, -0.1, 1.0, 1.0, qp) == 1
+    assert lib.d2pc_set_min_disparity(None, 1.0) == 1

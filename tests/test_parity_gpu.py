@@ -343,3 +343,17 @@ def test_calibration_blob_roundtrip(q_default):
         assert (cfg.border, cfg.mode) == (13, d2pc.MODE_COMPACT)
         with pytest.raises(d2pc.D2pcError):
             b.import_calibration(blob[:-1])
+
+
+def test_disparity_image_style_calibration_and_threshold():
+    """SURVEY section 8(f) #3: f, T, min_disparity carried by the message."""
+    q = d2pc.make_q_disparity_image(520.0, 0.11, 319.5, 239.5)
+    disp = synth_disparity(3, 9, 640, 480, "holes")
+    with ctx_for(q, mode=d2pc.MODE_COMPACT) as ctx:
+        ctx.set_min_disparity(2.0)
+        gp, gi = ctx.process(disp, want_index=True)
+    wp, wi = oracle.reproject_compact(disp, q, border=40, min_disparity=2.0)
+    assert np.array_equal(gi, wi)
+    assert_points_close(gp, wp, max_ulp=MAX_ULP)
+    z = 520.0 * 0.11 / disp.reshape(-1)[gi].astype(np.float64)
+    assert np.allclose(gp[:, 2], z, rtol=2e-7)
