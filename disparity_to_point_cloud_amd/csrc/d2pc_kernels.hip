@@ -688,6 +688,14 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
   D2PC_DECLARE_STRIPS(VEC, wave < kBlock / 64 ? wave : 0u);
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
   uint32_t spin_acc = 0;
+#ifdef D2PC_DIAG
+  // phase timers (shader clock), lane 0 of worker wave 0 and of the control wave; named
+  // scalars on purpose: a runtime-indexed array would live in scratch and distort the run
+  unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, nIt = 0;
+#define D2PC_STAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define D2PC_STAMP(x)
+#endif
 
   for (uint32_t f = blockIdx.x % g.n_frames; f < g.n_frames; f += gridDim.x) {
     const FrameState fs(state, g, f);
@@ -719,6 +727,7 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
     for (uint32_t it = 0; cur != kNoTile || prev != kNoTile; ++it) {
       const uint32_t slot = it & 1u;
       uint64_t mask[PXT];
+      D2PC_STAMP(c0);
       if (ctl) {
         // ticket of the tile after `cur`, and the prefix of `prev`
         if (cur != kNoTile && lane == 0) s_next[slot] = atomicAdd(fs.ticket, 1u);
@@ -733,7 +742,9 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
           for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = uint32_t(__popcll(mask[k]));
         }
       }
+      D2PC_STAMP(c1);
       __syncthreads();
+      D2PC_STAMP(c2);
       if (ctl && cur != kNoTile) {
         uint32_t total;
         const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
@@ -748,6 +759,7 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
         }
       }
       __syncthreads();
+      D2PC_STAMP(c3);
       uint32_t next = kNoTile;
       if (cur != kNoTile) {
         next = s_next[slot];
@@ -788,14 +800,35 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
 #pragma unroll
         for (int k = 0; k < PXT; ++k) dc[k] = dn[k];
       }
+#ifdef D2PC_DIAG
+      {
+        D2PC_STAMP(c4);
+        tA += c1 - c0;  // worker: count phase            | control: ticket + prefix
+        tB += c2 - c1;  // waiting at barrier 1 for the other side
+        tC += c3 - c2;  // worker: waits for scan/publish | control: scan + publish (+ barrier 2)
+        tD += c4 - c3;  // worker: next loads + reproject + scatter
+        ++nIt;
+      }
+#endif
       prev = cur;
       cur = next;
     }
     __syncthreads();
   }
 #ifdef D2PC_DIAG
-  if (ctl && lane == 0) atomicAdd(&hdr->diag[1], (unsigned long long)spin_acc);
+  if (lane == 0 && wave == 0) {
+    atomicAdd(&hdr->diag[0], nIt);
+    atomicAdd(&hdr->diag[2], tA);
+    atomicAdd(&hdr->diag[3], tB);
+    atomicAdd(&hdr->diag[4], tC);
+    atomicAdd(&hdr->diag[5], tD);
+  }
+  if (lane == 0 && ctl) {
+    atomicAdd(&hdr->diag[1], (unsigned long long)spin_acc);
+    atomicAdd(&hdr->diag[6], tA);  // control: ticket + prefix
+  }
 #endif
+#undef D2PC_STAMP
 }
 
 // --------------------------------------------------------------------------

@@ -14,10 +14,10 @@ from disparity_to_point_cloud_amd.torch_api import DeviceBatch
 lib = d2pc.load_library()
 hip = ctypes.CDLL("libamdhip64.so.7")
 q = d2pc.make_q()
-for pxt in (4, 8):
-    for bpc in (6, 16):
+for pxt in (8, 16):
+    for bpc in (2, 3, 5):
         ctx = d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=2)
-        ctx.set_tuning("pxt_compact", pxt); ctx.set_tuning("blocks_per_cu", bpc)
+        ctx.set_tuning("pxt_compact", pxt); ctx.set_tuning("onepass_blocks_per_cu", bpc)
         b = DeviceBatch(ctx, 16, 2160, 3840)
         b.disp.copy_(torch.rand(b.disp.shape, device="cuda") * 127.5 + 0.5)
         for _ in range(3):
@@ -31,9 +31,9 @@ for pxt in (4, 8):
         buf = (ctypes.c_ulonglong * 8)()
         lib.d2pc_debug_read_header.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.d2pc_debug_read_header(ctx.handle, buf)
-        its, spins, w1, wb, w3, c1, cb = [buf[i] for i in range(1, 8)]
+        its, spins, wA, wB, wC, wD, cA = [buf[i] for i in range(1, 8)]
         its = max(its, 1)
         print(f"pxt={pxt:2d} bpc={bpc:2d} kernel={e0.elapsed_time(e1)*1e3:8.1f}us iterations={its} spins/it={spins/its:6.2f} "
-              f"cycles/it worker: compute={w1/its:7.0f} barrier1-wait={wb/its:7.0f} rest={w3/its:7.0f} | "
-              f"control: ticket+poll={c1/its:7.0f} barrier1-wait={cb/its:7.0f}", flush=True)
+              f"cycles/it worker: count={wA/its:6.0f} barrier1={wB/its:6.0f} scan-wait={wC/its:6.0f} loads+scatter={wD/its:6.0f} "
+              f"sum={(wA+wB+wC+wD)/its:6.0f} | control ticket+prefix={cA/its:6.0f}", flush=True)
         ctx.close()
