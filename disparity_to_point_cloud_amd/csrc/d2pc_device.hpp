@@ -92,6 +92,6 @@ constexpr uint32_t kFrameTicketBytes = 256;   // the ticket word has a 256-B blo
 constexpr uint32_t kGroupAccStride = 128;     // one group accumulator per 128-B line
 constexpr uint64_t kGranuleTag = uint64_t(1) << 63;
 constexpr int kGroupTiles = 64;         // tiles per counting group
-constexpr uint32_t kSpinLimit = 1u << 20;
+constexpr uint32_t kSpinLimit = 1u << 18;     // polls with back-off: a fraction of a second
 
 }  // namespace d2pc

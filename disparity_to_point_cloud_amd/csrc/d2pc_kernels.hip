@@ -423,7 +423,11 @@ __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, Sta
         v = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = ready(v);
       }
-      if (++spins > kSpinLimit) {
+      // bounded: give up after kSpinLimit polls, and as soon as ANY wave of the
+      // launch has given up (sticky flag), so a broken launch drains in about a
+      // second instead of timing out tile by tile; the host then sees the flag
+      if (++spins > kSpinLimit ||
+          ((spins & 63u) == 0 && __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         if (lane == 0) __hip_atomic_store(&hdr->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -707,32 +711,34 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
     __syncthreads();
     uint32_t cur = s_next[1];
     if (cur >= g.tiles_per_frame) cur = kNoTile;
-    uint32_t prev = kNoTile;
+    uint32_t prev = kNoTile;   // counted in the previous iteration
+    uint32_t prev2 = kNoTile;  // counted two iterations ago: scattered now.  The lag gives every
+                               // predecessor a whole extra iteration to publish before it is polled
     KnownGroups known;  // control wave: prefix of the frame's complete groups seen so far
 
     float dc[PXT];  // tile `cur`: disparities (loads in flight until the count phase)
-    float dp[PXT];  // tile `prev`: disparities, counted and published, waiting for its prefix
-    uint64_t pmask[PXT];
-    uint32_t pexcl[PXT];
-    uint32_t ptotal = 0;
+    float dp[PXT], dq[PXT];  // tiles `prev` / `prev2`: disparities, counted and published
+    uint64_t pmask[PXT], qmask[PXT];
+    uint32_t pexcl[PXT], qexcl[PXT];
+    uint32_t ptotal = 0, qtotal = 0;
 #pragma unroll
     for (int k = 0; k < PXT; ++k) {
-      dc[k] = dp[k] = 0.f;
-      pmask[k] = 0;
-      pexcl[k] = 0;
+      dc[k] = dp[k] = dq[k] = 0.f;
+      pmask[k] = qmask[k] = 0;
+      pexcl[k] = qexcl[k] = 0;
     }
     if (!ctl && cur != kNoTile)
       tile_load_d<DT, PXT, VEC>(dc, fin, g, cur * uint32_t(kBlock * PXT), wave, lane, wave_strip);
 
-    for (uint32_t it = 0; cur != kNoTile || prev != kNoTile; ++it) {
+    for (uint32_t it = 0; cur != kNoTile || prev != kNoTile || prev2 != kNoTile; ++it) {
       const uint32_t slot = it & 1u;
       uint64_t mask[PXT];
       D2PC_STAMP(c0);
       if (ctl) {
         // ticket of the tile after `cur`, and the prefix of `prev`
         if (cur != kNoTile && lane == 0) s_next[slot] = atomicAdd(fs.ticket, 1u);
-        if (prev != kNoTile) {
-          const uint32_t p = prefix_before<true>(fs, hdr, prev, lane, spin_acc, known);
+        if (prev2 != kNoTile) {
+          const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, spin_acc, known);
           if (lane == 0) s_prefix[slot] = p;
         }
       } else if (cur != kNoTile) {
@@ -772,21 +778,29 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
         for (int k = 0; k < PXT; ++k) dn[k] = 0.f;
         if (next != kNoTile)
           tile_load_d<DT, PXT, VEC>(dn, fin, g, next * uint32_t(kBlock * PXT), wave, lane, wave_strip);
-        if (prev != kNoTile) {
+        if (prev2 != kNoTile) {
           const uint32_t prefix = s_prefix[slot];
           uint32_t uu[PXT], vv[PXT];
-          tile_coords<PXT>(uu, vv, g, prev * uint32_t(kBlock * PXT), wave, lane);
+          tile_coords<PXT>(uu, vv, g, prev2 * uint32_t(kBlock * PXT), wave, lane);
 #pragma unroll
           for (int k = 0; k < PXT; ++k) {
             float X, Y, Z;
-            reproject(Q, uu[k], vv[k], dp[k], X, Y, Z);
-            const uint32_t pos = prefix + pexcl[k] + mbcnt64(pmask[k]);
-            if (((pmask[k] >> lane) & 1) && pos < g.roi_n) {
+            reproject(Q, uu[k], vv[k], dq[k], X, Y, Z);
+            const uint32_t pos = prefix + qexcl[k] + mbcnt64(qmask[k]);
+            if (((qmask[k] >> lane) & 1) && pos < g.roi_n) {
               store_point(fout, pos, X, Y, Z);
               if (fidx) store_index(fidx, pos, vv[k] * g.width + uu[k]);
             }
           }
-          if (counts && prev == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + ptotal;
+          if (counts && prev2 == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + qtotal;
+        }
+        // prev -> prev2
+        qtotal = ptotal;
+#pragma unroll
+        for (int k = 0; k < PXT; ++k) {
+          dq[k] = dp[k];
+          qmask[k] = pmask[k];
+          qexcl[k] = pexcl[k];
         }
         if (cur != kNoTile) {
           ptotal = s_total[slot];
@@ -810,6 +824,7 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
         ++nIt;
       }
 #endif
+      prev2 = prev;
       prev = cur;
       cur = next;
     }

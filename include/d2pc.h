@@ -67,9 +67,10 @@ typedef struct d2pc_config {
   int32_t border;         /* ROI inset on all four sides; cpp:70,72 => 40     */
   int32_t mode;           /* d2pc_mode                                        */
   float min_disparity;    /* COMPACT only: also drop d <= this; -inf = off    */
-  int32_t compact_algo;   /* 0 = library default (two-pass); 1 = two-pass
-                             count/scatter; 2 = single-pass counted hand-off
-                             (experimental)                                   */
+  int32_t compact_algo;   /* 0 = library default (single pass for batches of
+                             >= 8 frames, two-pass below); 1 = two-pass
+                             count/scan/scatter; 2 = single-pass counted
+                             hand-off                                         */
   int32_t reserved[4];
 } d2pc_config;
 
@@ -233,8 +234,10 @@ int d2pc_pipeline_release(d2pc_ctx *ctx, int slot);
  * width x height and batches up to n_frames. */
 int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames);
 
-/* COMPACT single-pass only: after the stream has been synchronised, returns
- * D2PC_ERR_INTERNAL if any bounded hand-off spin expired in the last launch. */
+/* After the stream of a COMPACT d2pc_process_device call has been
+ * synchronised: D2PC_ERR_INTERNAL if a bounded hand-off wait of the single-pass
+ * kernel expired in the last launch (its output is then incomplete; relaunch
+ * with compact_algo = 1).  The synchronous entry points check this themselves. */
 int d2pc_check_async_error(d2pc_ctx *ctx);
 
 /* Launch-shape tuning hook (no counterpart in the reference; results never

@@ -55,6 +55,24 @@ def test_c4_4k_compact_batch(algo):
         assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"4K compact frame {f}")
 
 
+def test_default_algorithm_on_a_large_batch():
+    """compact_algo = 0 picks the single pass for >= 8 frames: 12 frames of
+    1920x1080 with three validity patterns, relaunched, against the oracle."""
+    q = d2pc.make_q()
+    kinds = ["holes", "blocky", "uniform"]
+    frames = [synth_disparity(3, 40 + f, 1920, 1080, kinds[f % 3]) for f in range(12)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        b = _batch(ctx, frames, want_index=True)
+        for _ in range(2):
+            b.launch()
+        res = b.results()
+        ctx.check_async_error()
+    for f, (pts, idx) in enumerate(res):
+        wp, wi = oracle.reproject_compact(frames[f], q, border=40)
+        assert np.array_equal(idx, wi), f"frame {f}"
+        assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"frame {f}")
+
+
 def test_batch_u8_native_geometry():
     q = d2pc.make_q()
     rng = np.random.default_rng(21)
