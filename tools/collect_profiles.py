@@ -91,11 +91,13 @@ if main:
         def mean_of(path, ctr, kern):
             vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kern in r["Kernel_Name"] and r["Counter_Name"] == ctr]
             return sum(vals) / len(vals) if vals else 0.0
-        rb = sum(mean_of(cf, "FETCH_SIZE", k) for k in ("k_compact_count", "k_compact_scan", "k_compact_scatter")) * 1024 * round(fetch_factor, 3)
-        wb = sum(mean_of(cw, "WRITE_SIZE", k) for k in ("k_compact_count", "k_compact_scan", "k_compact_scatter")) * 1024
+        kerns = ("k_compact_count", "k_compact_scan", "k_compact_scatter", "k_compact_onepass")
+        rb = sum(mean_of(cf, "FETCH_SIZE", k) for k in kerns) * 1024 * round(fetch_factor, 3)
+        wb = sum(mean_of(cw, "WRITE_SIZE", k) for k in kerns) * 1024
         traffic["compact_border40_frames16"] = {
             "hbm_bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb,
-            "source": f"profiles/{rnd}_pmc_summary.json (count + scan + scatter kernels; the count pass reads the input a second time)"}
+            "source": f"profiles/{rnd}_pmc_summary.json (all compaction kernels of one step: the single-pass kernel "
+                      f"for batches >= 8 frames, else count + scan + scatter)"}
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
 print(json.dumps(traffic, indent=1))
