@@ -109,9 +109,10 @@ def test_compact_is_idempotent_and_sorted_at_full_size():
     assert np.array_equal(roi, np.nonzero(keep)[0])
 
 
-def test_launch_on_side_stream_and_graph_capture():
+@pytest.mark.parametrize("n_frames", [4, 9])  # two-pass (count/scan/scatter) and single-pass (memset + kernel)
+def test_launch_on_side_stream_and_graph_capture(n_frames):
     q = d2pc.make_q()
-    frames = [synth_disparity(2, f, 640, 480, "holes") for f in range(4)]
+    frames = [synth_disparity(2, f, 640, 480, "holes") for f in range(n_frames)]
     with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
         b = _batch(ctx, frames, want_index=True)
         side = torch.cuda.Stream()
