@@ -41,19 +41,31 @@ __global__ __launch_bounds__(kBlock) void k_median_u8(const uint8_t *__restrict_
   uint8_t *fdst = dst + uint64_t(f) * a.dst_frame_stride;
 
   // ---- 1. bit planes of the tile's input rows, two rows per ballot ----------
+  // All of a wave's row loads are issued before the first is used: the loop
+  // is latency-bound otherwise (one ~2 us round trip per row pair, ten pairs).
   const int j = int(lane & 31u);
   int ix = c0 - R + j;
   ix = ix < 0 ? 0 : ix >= int(a.width) ? int(a.width) - 1 : ix;  // replicate
-  for (int rp = int(wave); rp < PAIRS; rp += kBlock / 64) {
-    int iy = y0 - R + 2 * rp + int(lane >> 5);
-    iy = iy < 0 ? 0 : iy >= int(a.height) ? int(a.height) - 1 : iy;
-    const uint32_t v = fsrc[uint64_t(iy) * a.src_row_stride + uint32_t(ix)];
+  constexpr int PER_WAVE = (PAIRS + kBlock / 64 - 1) / (kBlock / 64);
+  uint32_t v[PER_WAVE];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const uint64_t m = __ballot((v >> p) & 1u);
-      if (lane == 0) {
-        s_plane[p][2 * rp] = uint32_t(m);
-        s_plane[p][2 * rp + 1] = uint32_t(m >> 32);
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int rp = int(wave) + i * (kBlock / 64);
+    int iy = y0 - R + 2 * rp + int(lane >> 5);
+    iy = iy < 0 ? 0 : iy >= int(a.height) ? int(a.height) - 1 : iy;  // also keeps rp >= PAIRS in bounds
+    v[i] = fsrc[uint64_t(iy) * a.src_row_stride + uint32_t(ix)];
+  }
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int rp = int(wave) + i * (kBlock / 64);
+    if (rp < PAIRS) {  // wave-uniform
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const uint64_t m = __ballot((v[i] >> p) & 1u);
+        if (lane == 0) {
+          s_plane[p][2 * rp] = uint32_t(m);
+          s_plane[p][2 * rp + 1] = uint32_t(m >> 32);
+        }
       }
     }
   }

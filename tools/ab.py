@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--algos", default="1")
     ap.add_argument("--idx", type=int, default=0)
     ap.add_argument("--holes", type=float, default=0.0)
+    ap.add_argument("--blocky", type=int, default=0, help="holes come in 64x64 blocks instead of iid pixels")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--frames", type=int, default=16)
@@ -36,7 +37,11 @@ def main():
     import disparity_to_point_cloud_amd as d2pc
     g = torch.Generator(device="cuda").manual_seed(1)
     disp = torch.rand((a.frames, 2160, 3840), generator=g, device="cuda") * 127.5 + 0.5
-    if a.holes > 0:
+    if a.holes > 0 and a.blocky:
+        m = (torch.rand((a.frames, (2160 + 63) // 64, (3840 + 63) // 64), generator=g, device="cuda") >= a.holes).float()
+        m = m.repeat_interleave(64, dim=1).repeat_interleave(64, dim=2)[:, :2160, :3840]
+        disp.mul_(m)
+    elif a.holes > 0:
         disp.mul_((torch.rand(disp.shape, generator=g, device="cuda") >= a.holes).float())
     cands = []
     # ONE set of buffers for every candidate: kernel time depends on which
