@@ -1,7 +1,8 @@
 // replay_main.cpp -- ROS-free harness around Disparity2PCloud::DisparityCb.
 //   d2pc_replay prep  <in.raw> <w> <h> <mono8|mono16> <out.raw>
 //        host plumbing only (toCvCopy + medianBlur 11): no GPU needed
-//   d2pc_replay cloud <in.raw> <w> <h> <mono8|mono16> <out.bin> [compact] [hostmedian]
+//   d2pc_replay cloud <in.raw> <w> <h> <mono8|mono16> <out.bin> [compact] [hostmedian] [name=value ...]
+//        name=value sets a private parameter (~fx_ ~fy_ ~cx_ ~cy_ ~base_line_), as a launch file would
 //        full callback; writes PointCloud2 metadata (text) then the payload
 // <in.raw> holds the sensor_msgs/Image data bytes (row-major, step = w*bpp).
 #include <cstdio>
@@ -48,6 +49,10 @@ int main(int argc, char **argv) {
       d2pc_shim::PointCloud2 got;
       int published = 0;
       d2pc::ParamSource nh;  // d2pcloud.launch sets no params: defaults apply
+      for (int i = 7; i < argc; ++i) {
+        const char *eq = strchr(argv[i], '=');
+        if (eq) nh.values[std::string(argv[i], size_t(eq - argv[i]))] = atof(eq + 1);
+      }
       d2pc::Disparity2PCloudT<d2pc_shim::Msgs> node(
           nh, [&](const d2pc_shim::PointCloud2 &pc) { got = pc; ++published; }, 0, nullptr,
           has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false,

@@ -100,3 +100,21 @@ def test_c1_full_callback_640x480_mono16(replay, tmp_path, mode, median):
     assert m["is_bigendian"] == "0" and m["is_dense"] == ("0" if mode == "parity" else "1")
     assert m["frame_id"] == "/camera_optical_frame" and m["stamp"] == "1234.5678"
     assert kv[kv.index("fields") + 1:] == ["x:0:7:1", "y:4:7:1", "z:8:7:1"]
+
+
+@pytest.mark.gpu
+def test_private_parameters_reach_the_calibration(replay, tmp_path):
+    """hpp:84-88: ~fx_ ~fy_ ~cx_ ~cy_ ~base_line_ override the defaults and end up in Q."""
+    import disparity_to_point_cloud_amd as d2pc
+
+    rng = np.random.default_rng(31)
+    img = rng.integers(1, 256, size=(200, 300)).astype(np.uint8)
+    params = dict(fx=500.0, fy=505.5, cx=150.25, cy=99.0, baseline=0.043)
+    p, dst = _run(replay, "cloud", img, "mono8", tmp_path, "hostmedian", "fx_=500.0", "fy_=505.5", "cx_=150.25",
+                  "cy_=99.0", "base_line_=0.043")
+    assert p.returncode == 0, p.stderr
+    payload = dst.read_bytes().split(b"\n", 1)[1]
+    pts = np.frombuffer(payload, dtype=np.float32).reshape(-1, 4)
+    q = d2pc.make_q(nx=752, ny=480, **params)  # hpp:101-103: rectification size stays 752x480
+    want = oracle.reproject(oracle.median_u8(img, 11), q, border=40, scale=0.125)
+    assert_points_close(pts, want, max_ulp=1, rel=1e-5, what="custom calibration")
