@@ -67,10 +67,10 @@ typedef struct d2pc_config {
   int32_t border;         /* ROI inset on all four sides; cpp:70,72 => 40     */
   int32_t mode;           /* d2pc_mode                                        */
   float min_disparity;    /* COMPACT only: also drop d <= this; -inf = off    */
-  int32_t compact_algo;   /* 0 = library default (single pass for batches of
-                             >= 8 frames, two-pass below); 1 = two-pass
-                             count/scan/scatter; 2 = single-pass counted
-                             hand-off                                         */
+  int32_t compact_algo;   /* 0 = library default (single pass for launches of
+                             >= 4 frames and >= ~25k tiles, two-pass below);
+                             1 = two-pass count/scan/scatter; 2 = single-pass
+                             counted hand-off                                 */
   int32_t reserved[4];
 } d2pc_config;
 

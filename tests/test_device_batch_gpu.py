@@ -56,11 +56,12 @@ def test_c4_4k_compact_batch(algo):
 
 
 def test_default_algorithm_on_a_large_batch():
-    """compact_algo = 0 picks the single pass for >= 8 frames: 12 frames of
-    1920x1080 with three validity patterns, relaunched, against the oracle."""
+    """compact_algo = 0 picks the single pass for big launches (>= 4 frames,
+    >= ~25k tiles): 30 frames of 1920x1080 (27k tiles) with three validity
+    patterns, relaunched, against the oracle."""
     q = d2pc.make_q()
     kinds = ["holes", "blocky", "uniform"]
-    frames = [synth_disparity(3, 40 + f, 1920, 1080, kinds[f % 3]) for f in range(12)]
+    frames = [synth_disparity(3, 40 + f, 1920, 1080, kinds[f % 3]) for f in range(30)]
     with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
         b = _batch(ctx, frames, want_index=True)
         for _ in range(2):
@@ -109,11 +110,11 @@ def test_compact_is_idempotent_and_sorted_at_full_size():
     assert np.array_equal(roi, np.nonzero(keep)[0])
 
 
-@pytest.mark.parametrize("n_frames", [4, 9])  # two-pass (count/scan/scatter) and single-pass (memset + kernel)
-def test_launch_on_side_stream_and_graph_capture(n_frames):
+@pytest.mark.parametrize("algo", [1, 2])  # count/scan/scatter nodes | memset + single-pass kernel nodes
+def test_launch_on_side_stream_and_graph_capture(algo):
     q = d2pc.make_q()
-    frames = [synth_disparity(2, f, 640, 480, "holes") for f in range(n_frames)]
-    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+    frames = [synth_disparity(2, f, 640, 480, "holes") for f in range(6)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
         b = _batch(ctx, frames, want_index=True)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -32,21 +32,24 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--opbpc", type=int, default=4, help="single-pass kernel: persistent blocks per CU")
+    ap.add_argument("--w", type=int, default=3840)
+    ap.add_argument("--h", type=int, default=2160)
     a = ap.parse_args()
     from disparity_to_point_cloud_amd.torch_api import DeviceBatch
     import disparity_to_point_cloud_amd as d2pc
     g = torch.Generator(device="cuda").manual_seed(1)
-    disp = torch.rand((a.frames, 2160, 3840), generator=g, device="cuda") * 127.5 + 0.5
+    disp = torch.rand((a.frames, a.h, a.w), generator=g, device="cuda") * 127.5 + 0.5
     if a.holes > 0 and a.blocky:
-        m = (torch.rand((a.frames, (2160 + 63) // 64, (3840 + 63) // 64), generator=g, device="cuda") >= a.holes).float()
-        m = m.repeat_interleave(64, dim=1).repeat_interleave(64, dim=2)[:, :2160, :3840]
+        m = (torch.rand((a.frames, (a.h + 63) // 64, (a.w + 63) // 64), generator=g, device="cuda") >= a.holes).float()
+        m = m.repeat_interleave(64, dim=1).repeat_interleave(64, dim=2)[:, :a.h, :a.w]
         disp.mul_(m)
     elif a.holes > 0:
         disp.mul_((torch.rand(disp.shape, generator=g, device="cuda") >= a.holes).float())
     cands = []
     # ONE set of buffers for every candidate: kernel time depends on which
     # physical pages a buffer got (+-6 % between allocations of one process)
-    W, H, F = 3840, 2160, a.frames
+    W, H, F = a.w, a.h, a.frames
     stride = (W * H + 15) // 16 * 16
     points = torch.empty((F, stride, 4), dtype=torch.float32, device="cuda")
     index = torch.empty((F, stride), dtype=torch.int32, device="cuda") if a.idx else None
@@ -68,8 +71,7 @@ def main():
             ctx = capi.Context(q=capi.make_q(), border=int(border), mode=m, compact_algo=int(algo))
             ctx.set_tuning("pxt_parity", int(pxt)); ctx.set_tuning("pxt_compact", int(pxt))
             ctx.set_tuning("blocks_per_cu", int(bpc)); ctx.set_tuning("no_vec_rows", int(nv))
-            if int(algo) == 2:
-                ctx.set_tuning("onepass_blocks_per_cu", min(int(bpc), 64))
+            ctx.set_tuning("onepass_blocks_per_cu", a.opbpc)
             b = Cand(ctx)
             b.launch(); torch.cuda.synchronize()
             npts = int(counts.sum().item())
