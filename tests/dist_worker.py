@@ -61,6 +61,30 @@ def main():
             assert np.array_equal(gi, wi)
             assert_points_close(gp, wp, max_ulp=1, rel=1e-5, what=f"rank {rank} frame {f}")
         ctx.close()
+
+        # one shared stream of 11 frames sharded over the ranks' frame queues
+        # (pipelined host path, several frames in flight per rank)
+        from disparity_to_point_cloud_amd.stream import run_sharded
+
+        shared = [synth_disparity(6, i, 320 + 16 * (i % 3), 240, "holes") for i in range(11)]
+        ctx2 = d2pc.Context(device_id=0)
+        ctx2.import_calibration(blob)
+        seen = {}
+
+        def on_cloud(tag, pts, idx):
+            seen[tag] = (pts.copy(), idx.copy())
+
+        tot = run_sharded(ctx2, shared, on_cloud, want_index=True)
+        ctx2.close()
+        assert sorted(seen) == multi_gpu.shard_frames(11, rank, world)
+        npts = 0
+        for i, (pts, idx) in seen.items():
+            wp, wi = oracle.reproject_compact(shared[i], q0, border=24)
+            assert np.array_equal(idx, wi)
+            assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"sharded frame {i}")
+        want_total = sum(len(oracle.reproject_compact(fr, q0, border=24)[0]) for fr in shared)
+        assert tot["frames"] == 11 and tot["points"] == want_total, tot
+        assert tot["pixels"] == sum(fr.size for fr in shared)
     multi_gpu.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}/{world} ok")
