@@ -26,4 +26,16 @@ from .capi import (  # noqa: F401
     make_q_disparity_image,
     roi_points,
     status_string,
+    FuseDesc,
+    fuse_desc_init,
+    crop_to_square,
+    FUSE_WEIGHTED_AVERAGE,
+    FUSE_MAX_DIST,
+    FUSE_MAX_DIST_UNLESS_BLACK,
+    FUSE_BETTER_SCORE,
+    FUSE_ONLY_GOOD_1,
+    FUSE_ONLY_GOOD_AVG,
+    FUSE_OVERLAP,
+    FUSE_BLACK_TO_WHITE,
+    FUSE_GRAD_FILTER,
 )

@@ -24,8 +24,11 @@ ABI_SYMBOLS = [
     "d2pc_roi_points", "d2pc_cloud_meta_fill", "d2pc_process", "d2pc_process_device", "d2pc_reserve",
     "d2pc_check_async_error", "d2pc_set_tuning", "d2pc_median_device", "d2pc_process_mono8",
     "d2pc_pipeline_configure", "d2pc_pipeline_acquire", "d2pc_pipeline_submit", "d2pc_pipeline_collect",
-    "d2pc_pipeline_release",
+    "d2pc_pipeline_release", "d2pc_fuse_desc_init", "d2pc_fuse_device", "d2pc_crop_to_square",
 ]
+# d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
+(FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
+ FUSE_ONLY_GOOD_AVG, FUSE_OVERLAP, FUSE_BLACK_TO_WHITE, FUSE_GRAD_FILTER) = range(9)
 
 
 class Config(ctypes.Structure):
@@ -58,6 +61,17 @@ class FrameDesc(ctypes.Structure):
         ("dtype", ctypes.c_int32), ("scale", ctypes.c_float), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
         ("row_stride_bytes", ctypes.c_size_t), ("median_ksize", ctypes.c_int32), ("want_index", ctypes.c_int32),
         ("tag", ctypes.c_uint64),
+    ]
+
+
+class FuseDesc(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("rule", ctypes.c_int32), ("width", ctypes.c_int32),
+        ("height", ctypes.c_int32), ("n_frames", ctypes.c_int32), ("crop_left", ctypes.c_int32),
+        ("crop_right", ctypes.c_int32), ("crop_top", ctypes.c_int32), ("crop_bottom", ctypes.c_int32),
+        ("planes", ctypes.c_void_p * 6), ("pitch", ctypes.c_size_t * 6), ("frame_stride", ctypes.c_size_t * 6),
+        ("fused", ctypes.c_void_p), ("fused_pitch", ctypes.c_size_t), ("fused_frame_stride", ctypes.c_size_t),
+        ("combined", ctypes.c_void_p), ("combined_pitch", ctypes.c_size_t), ("combined_frame_stride", ctypes.c_size_t),
     ]
 
 
@@ -133,6 +147,10 @@ def load_library():
                                         ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint64)]
     L.d2pc_pipeline_release.argtypes = [vp, ctypes.c_int]
     L.d2pc_reserve.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.d2pc_fuse_desc_init.argtypes = [ctypes.POINTER(FuseDesc)]
+    L.d2pc_fuse_desc_init.restype = None
+    L.d2pc_fuse_device.argtypes = [vp, ctypes.POINTER(FuseDesc), vp]
+    L.d2pc_crop_to_square.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)] * 3
     L.d2pc_check_async_error.argtypes = [vp]
     L.d2pc_set_tuning.argtypes = [vp, cp, ctypes.c_int]
     for name in ABI_SYMBOLS:
@@ -341,6 +359,10 @@ class Context:
                                                n_frames, d_dst_ptr, dst_row_stride, dst_frame_stride, ksize,
                                                stream_ptr))
 
+    def fuse_device(self, desc: "FuseDesc", stream_ptr=None):
+        """d2pc_fuse_device: fusion rule + combined confidence + 3x3 median + crop on device planes."""
+        self._check(self._L.d2pc_fuse_device(self._h, ctypes.byref(desc), stream_ptr))
+
     # -- pipelined host path (d2pc_pipeline_*) ------------------------------
     def pipeline_configure(self, depth=3, direct_host_write=False):
         self._check(self._L.d2pc_pipeline_configure(self._h, depth, int(direct_host_write)))
@@ -387,3 +409,20 @@ class Context:
                                          in_frame_stride, n_frames, d_out_ptr, d_index_ptr,
                                          out_frame_stride_points, d_counts_ptr, stream_ptr)
         self._check(st)
+
+
+def fuse_desc_init() -> FuseDesc:
+    d = FuseDesc()
+    load_library().d2pc_fuse_desc_init(ctypes.byref(d))
+    return d
+
+
+def crop_to_square(cols, rows, offset_x=0, offset_y=0, member_offset_y=None):
+    """d2pc_crop_to_square -> (x, y, n); raises D2pcError when the square leaves the image."""
+    x, y, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    st = load_library().d2pc_crop_to_square(cols, rows, offset_x, offset_y,
+                                   offset_y if member_offset_y is None else member_offset_y,
+                                   ctypes.byref(x), ctypes.byref(y), ctypes.byref(n))
+    if st != 0:
+        raise D2pcError(st, "crop_to_square(%d,%d,%d,%d)" % (cols, rows, offset_x, offset_y))
+    return x.value, y.value, n.value

@@ -1,0 +1,291 @@
+// d2pc_fusion.hip -- the depth-map fusion inner loop on gfx950
+// (SURVEY.md section 8(f) #4): per-pixel fusion rule + combined confidence
+// (reference src/depth_map_fusion.cpp:113-123, rules :162-235), 3x3 median of
+// the fused image (:124) and the border crop (:130), in ONE pass over HBM:
+// 6 bytes read and ~2 written per pixel, no intermediate image.
+//
+// Register-rolling stencil, no LDS, no barriers, no divergent branches.  The
+// unit of work is a WAVE: a strip of 248 columns by R rows.  Lane l holds 4
+// adjacent pixels (one dword per plane per row), lanes 0 and 63 are the
+// left/right halo columns, so a row of a strip is one 256-byte coalesced load
+// per plane.  All arithmetic is done on PAIRS: a dword is split once into its
+// even and odd bytes (two 16-bit fields each), after which v_pk_*_u16
+// instructions handle two pixels per lane per instruction:
+//  * the rule: every comparison a < b is the sign of the 16-bit difference
+//    a - b; the signs of one condition chain are AND-ed and expanded to a field
+//    mask with one arithmetic shift; the result is picked with bit-selects;
+//  * the 3x3 median, separable in the usual way: sort every vertical triple
+//    once (shared by three output pixels), fetch the neighbouring lanes' edge
+//    columns with DPP wave shifts, take med3(max3(lows), med3(mids),
+//    min3(highs)).
+// Borders replicate by clamping the LOAD coordinates (the rule is per pixel,
+// so that equals replicating the fused image, which is what cv::medianBlur's
+// BORDER_REPLICATE sees).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "d2pc_launch.hpp"
+
+namespace d2pc {
+
+namespace {
+
+constexpr int kStripCols = 248;  // output columns per wave: 62 lanes x 4 pixels
+
+// ---- two 16-bit fields per dword -------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk(uint32_t c) { return c | (c << 16); }  // both fields = c
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {         // per-field a - b (wraps)
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+// field mask (0xffff / 0) from the sign bit of each field.  Inline asm: written
+// as a vector shift, LLVM turns mask-and-pick into per-field compare + select,
+// which has no packed form and costs five instructions instead of one.
+__device__ __forceinline__ uint32_t pk_sign_mask(uint32_t a) {
+  uint32_t r;
+  asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_half(uint32_t a) {  // per-field a >> 1
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) >> 1);
+}
+__device__ __forceinline__ uint32_t pick(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+__device__ __forceinline__ uint32_t pk_med3(uint32_t a, uint32_t b, uint32_t c) {
+  return pk_max(pk_min(a, b), pk_min(pk_max(a, b), c));
+}
+// lane i receives lane i-1's / lane i+1's value (the wave's end lanes keep their own)
+__device__ __forceinline__ uint32_t from_left_lane(uint32_t v) {
+  return uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t from_right_lane(uint32_t v) {
+  return uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+// Where a lane finds its pixels x .. x+3 (columns outside [0, w) replicate the
+// edge pixel): ONE dword at the in-range column `col`, then two byte shuffles
+// (v_perm_b32) that fix up the edge lanes and split the dword into its even
+// and odd pixels in one go.  Needs w >= 4; narrower images gather bytes.
+struct LaneCols {
+  uint32_t col;          // dword load position (w >= 4)
+  uint32_t selE, selO;   // v_perm_b32 selectors -> pixels (0,2) / (1,3) as 16-bit fields
+  uint32_t xs[4];        // clamped columns (w < 4 only)
+};
+__device__ __forceinline__ LaneCols lane_cols(int x, int w) {
+  LaneCols c;
+  c.col = uint32_t(min(max(x, 0), max(w - 4, 0)));
+  uint32_t sel[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c.xs[k] = uint32_t(min(max(x + k, 0), w - 1));
+    sel[k] = (c.xs[k] - c.col) & 3u;
+  }
+  constexpr uint32_t kZero = 0x0cu;  // v_perm_b32: constant 0x00
+  c.selE = sel[0] | (kZero << 8) | (sel[2] << 16) | (kZero << 24);
+  c.selO = sel[1] | (kZero << 8) | (sel[3] << 16) | (kZero << 24);
+  return c;
+}
+struct Px4 {
+  uint32_t e, o;  // pixels (0,2) and (1,3), one 16-bit field each
+};
+// `row` is wave-uniform (scalar base + 32-bit lane offset addressing).
+template <bool NARROW>
+__device__ __forceinline__ Px4 load_px4(const uint8_t *__restrict__ row, const LaneCols &c) {
+  Px4 r;
+  if (!NARROW) {
+    uint32_t v;
+    __builtin_memcpy(&v, row + c.col, 4);
+    r.e = __builtin_amdgcn_perm(v, v, c.selE);
+    r.o = __builtin_amdgcn_perm(v, v, c.selO);
+  } else {
+    r.e = uint32_t(row[c.xs[0]]) | (uint32_t(row[c.xs[2]]) << 16);
+    r.o = uint32_t(row[c.xs[1]]) | (uint32_t(row[c.xs[3]]) << 16);
+  }
+  return r;
+}
+
+// The selected rule (reference src/depth_map_fusion.cpp:162-235) on a pair of
+// pixels; every operand field holds an 8-bit value.  lt(a, b) below is "the
+// sign bit of a - b", valid while |a - b| < 2^15.
+// GRAD_FILTER's float test 0.8 < float(d1)/float(d2) < 1.25 (cpp:224,230) is
+// 5*d1 >= 4*d2 && 4*d1 < 5*d2: the quotient is compared as a float against
+// DOUBLE literals, float(0.8) > 0.8 so the exact ratio 4/5 passes, 5/4 is exact
+// and fails, no other 8-bit ratio is within a float ulp of either bound, and
+// d2 == 0 (inf or NaN) fails both ways.
+template <int RULE>
+__device__ __forceinline__ uint32_t fuse_pair(uint32_t d1, uint32_t d2, uint32_t s1, uint32_t s2) {
+  const uint32_t avg = pk_half(d1 + d2);
+  switch (RULE) {
+    case FUSE_WEIGHTED_AVERAGE: {  // int weights: 1 for score 0, else 0; 0/0 (undefined there) -> 0
+      const uint32_t w1 = pk_sign_mask(pk_sub(s1, pk(1))), w2 = pk_sign_mask(pk_sub(s2, pk(1)));
+      return pick(w1, pick(w2, avg, d1), w2 & d2);
+    }
+    case FUSE_MAX_DIST: return pk_min(d1, d2);
+    case FUSE_MAX_DIST_UNLESS_BLACK: {
+      const uint32_t black = pk_sign_mask(pk_sub(d1, pk(1)) | pk_sub(d2, pk(1)));
+      return pick(black, pk_max(d1, d2), pk_min(d1, d2));
+    }
+    case FUSE_BETTER_SCORE: return pick(pk_sign_mask(pk_sub(s1, s2)), d1, d2);
+    case FUSE_ONLY_GOOD_1: return pk_sign_mask(pk_sub(s2, pk(50))) & d2;
+    case FUSE_ONLY_GOOD_AVG: return pk_sign_mask(pk_sub(s1, pk(100)) & pk_sub(s2, pk(100))) & avg;
+    case FUSE_OVERLAP: {
+      const uint32_t a = pk_sign_mask(pk_sub(s1, s2) & pk_sub(s1, pk(20)));
+      const uint32_t b = pk_sign_mask(pk_sub(s2, s1) & pk_sub(s2, pk(20)));
+      return pick(a, pk(150), b & pk(255));
+    }
+    case FUSE_BLACK_TO_WHITE: return pk(255) - s1;
+    default: {  // FUSE_GRAD_FILTER
+      const uint32_t a = pk_sign_mask(pk_sub(s1, s2) & pk_sub(s1, pk(100)) & pk_sub(d1, pk(230)));
+      const uint32_t b = pk_sign_mask(pk_sub(s2, s1) & pk_sub(s2, pk(100)) & pk_sub(d2, pk(230)));
+      const uint32_t d1x4 = d1 << 2, d2x4 = d2 << 2;
+      const uint32_t c = pk_sign_mask(~pk_sub(d1x4 + d1, d2x4) & pk_sub(d1x4, d2x4 + d2) & pk_sub(s1, pk(125)) &
+                                      pk_sub(s2, pk(125)));
+      return pick(a, d1, pick(b, d2, c & avg));
+    }
+  }
+}
+
+// Stores the bytes of v whose column lies in [lo, hi) at dst[x - lo].
+__device__ __forceinline__ void store_px4(uint8_t *__restrict__ dst_row, int x, int lo, int hi, uint32_t v) {
+  if (x >= lo && x + 3 < hi) {
+    __builtin_memcpy(dst_row + (x - lo), &v, 4);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (x + k >= lo && x + k < hi) dst_row[x + k - lo] = uint8_t(v >> (8 * k));
+}
+
+}  // namespace
+
+// One kernel per rule: with the rule as a run-time switch the unrolled body
+// outgrows the instruction cache.  NARROW = images less than 4 pixels wide.
+#ifndef D2PC_FUSE_WAVES_PER_EU
+#define D2PC_FUSE_WAVES_PER_EU 2
+#endif
+template <int RULE, int R, bool NARROW>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(D2PC_FUSE_WAVES_PER_EU)))
+void k_fuse_median3(const FuseArgs a) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t item = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (item >= a.items) return;  // wave-uniform
+  // the divisions run on the VALU; readfirstlane puts the (uniform) results back into SGPRs so that
+  // every row pointer below is a scalar base
+  const uint32_t rest = __builtin_amdgcn_readfirstlane(item / a.strips_x);
+  const uint32_t strip = item - rest * a.strips_x;
+  const uint32_t frame = __builtin_amdgcn_readfirstlane(rest / a.chunks_y);
+  const uint32_t chunk = rest - frame * a.chunks_y;
+  const int w = int(a.width), h = int(a.height);
+  const int x0 = int(strip) * kStripCols, y0 = int(chunk) * R;
+  const int x = x0 - 4 + int(lane) * 4;  // lane 0 = left halo, lane 63 = right halo
+  const LaneCols lc = lane_cols(x, w);
+
+  const uint8_t *pl[6];
+#pragma unroll
+  for (int p = 0; p < 6; ++p) pl[p] = a.in[p] + uint64_t(frame) * a.in_frame_stride[p];
+
+  const bool owner = lane >= 1u && lane <= 62u && x < w;  // halo lanes store nothing
+  uint8_t *cf = a.combined ? a.combined + uint64_t(frame) * a.combined_frame_stride : nullptr;
+
+  // ---- fused value of rows y0-1 .. y0+R (replicated at the image border), as
+  //      pairs: E = pixels (0,2), O = pixels (1,3) of the lane; the combined
+  //      confidence min(grad1, grad2) (cpp:118-121) of the strip's own rows goes
+  //      out on the way so that its loads overlap the rule arithmetic ----------
+  uint32_t selE[R + 2], selO[R + 2];
+#pragma unroll
+  for (int i = 0; i < R + 2; ++i) {
+    const int yu = y0 - 1 + i;
+    const int y = yu < 0 ? 0 : yu >= h ? h - 1 : yu;
+    const Px4 d1 = load_px4<NARROW>(pl[0] + uint32_t(y) * a.in_pitch[0], lc);  // plane extents < 4 GiB (host-checked)
+    const Px4 d2 = load_px4<NARROW>(pl[1] + uint32_t(y) * a.in_pitch[1], lc);
+    const Px4 s1 = load_px4<NARROW>(pl[2] + uint32_t(y) * a.in_pitch[2], lc);
+    const Px4 s2 = load_px4<NARROW>(pl[3] + uint32_t(y) * a.in_pitch[3], lc);
+    if (cf && i >= 1 && i <= R) {  // wave-uniform
+      const Px4 g1 = load_px4<NARROW>(pl[4] + uint32_t(y) * a.in_pitch[4], lc);
+      const Px4 g2 = load_px4<NARROW>(pl[5] + uint32_t(y) * a.in_pitch[5], lc);
+      const uint32_t m = pk_min(g1.e, g2.e) | (pk_min(g1.o, g2.o) << 8);
+      if (owner && yu < h) store_px4(cf + uint32_t(y) * a.combined_pitch, x, 0, w, m);
+    }
+    selE[i] = fuse_pair<RULE>(d1.e, d2.e, s1.e, s2.e);
+    selO[i] = fuse_pair<RULE>(d1.o, d2.o, s1.o, s2.o);
+  }
+
+  // ---- 3x3 median of the fused image, cropped store (cpp:124,130) -------------
+  uint8_t *ff = a.fused + uint64_t(frame) * a.fused_frame_stride;
+  const int cx0 = int(a.crop_left), cx1 = cx0 + int(a.out_width);
+  const int cy0 = int(a.crop_top), cy1 = cy0 + int(a.out_height);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    // sorted vertical triples of the lane's columns: E = columns (0,2), O = (1,3)
+    const uint32_t mnE = pk_min(selE[r], selE[r + 1]), mxE = pk_max(selE[r], selE[r + 1]);
+    const uint32_t mnO = pk_min(selO[r], selO[r + 1]), mxO = pk_max(selO[r], selO[r + 1]);
+    const uint32_t loE = pk_min(mnE, selE[r + 2]), hiE = pk_max(mxE, selE[r + 2]);
+    const uint32_t meE = pk_max(mnE, pk_min(mxE, selE[r + 2]));
+    const uint32_t loO = pk_min(mnO, selO[r + 2]), hiO = pk_max(mxO, selO[r + 2]);
+    const uint32_t meO = pk_max(mnO, pk_min(mxO, selO[r + 2]));
+    // columns (-1,1) and (2,4): column -1 is the left lane's column 3, column 4 the right lane's column 0
+    const uint32_t loL = __builtin_amdgcn_alignbit(loO, from_left_lane(loO), 16);
+    const uint32_t meL = __builtin_amdgcn_alignbit(meO, from_left_lane(meO), 16);
+    const uint32_t hiL = __builtin_amdgcn_alignbit(hiO, from_left_lane(hiO), 16);
+    const uint32_t loR = __builtin_amdgcn_alignbit(from_right_lane(loE), loE, 16);
+    const uint32_t meR = __builtin_amdgcn_alignbit(from_right_lane(meE), meE, 16);
+    const uint32_t hiR = __builtin_amdgcn_alignbit(from_right_lane(hiE), hiE, 16);
+    // outputs (0,2) see columns L,E,O; outputs (1,3) see columns E,O,R
+    const uint32_t outE = pk_med3(pk_max(pk_max(loL, loE), loO), pk_med3(meL, meE, meO), pk_min(pk_min(hiL, hiE), hiO));
+    const uint32_t outO = pk_med3(pk_max(pk_max(loE, loO), loR), pk_med3(meE, meO, meR), pk_min(pk_min(hiE, hiO), hiR));
+    const int y = y0 + r;
+    if (owner && y >= cy0 && y < cy1) store_px4(ff + uint32_t(y - cy0) * a.fused_pitch, x, cx0, cx1, outE | (outO << 8));
+  }
+}
+
+namespace {
+template <int RULE>
+void launch_rule(const FuseArgs &a, uint32_t rows, uint32_t grid, hipStream_t stream) {
+  if (a.width < 4)
+    hipLaunchKernelGGL((k_fuse_median3<RULE, 8, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+  else if (rows == 16)
+    hipLaunchKernelGGL((k_fuse_median3<RULE, 16, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+  else if (rows == 4)
+    hipLaunchKernelGGL((k_fuse_median3<RULE, 4, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+  else
+    hipLaunchKernelGGL((k_fuse_median3<RULE, 8, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+}
+}  // namespace
+
+// rows_hint: 0 = choose; 4, 8 or 16 = rows per wave (tuning).
+hipError_t launch_fuse(FuseArgs a, hipStream_t stream, int rows_hint) {
+  // Taller strips re-read fewer halo rows but need more registers (fewer waves
+  // in flight); small launches want more, shorter strips.
+  const uint32_t strips = (a.width + kStripCols - 1) / kStripCols;
+  uint32_t rows = (rows_hint == 4 || rows_hint == 8 || rows_hint == 16) ? uint32_t(rows_hint) : 0u;
+  if (!rows) rows = uint64_t(strips) * ((a.height + 15) / 16) * a.n_frames >= 8192u ? 16u : 8u;
+  if (a.width < 4) rows = 8;
+  a.strips_x = strips;
+  a.chunks_y = (a.height + rows - 1) / rows;
+  const uint64_t items = uint64_t(a.strips_x) * a.chunks_y * a.n_frames;
+  if (items == 0 || items > 0x7fffffffull) return hipErrorInvalidValue;
+  a.items = uint32_t(items);
+  const uint32_t grid = (a.items + kBlock / 64 - 1) / (kBlock / 64);
+  switch (a.rule) {
+    case FUSE_WEIGHTED_AVERAGE: launch_rule<FUSE_WEIGHTED_AVERAGE>(a, rows, grid, stream); break;
+    case FUSE_MAX_DIST: launch_rule<FUSE_MAX_DIST>(a, rows, grid, stream); break;
+    case FUSE_MAX_DIST_UNLESS_BLACK: launch_rule<FUSE_MAX_DIST_UNLESS_BLACK>(a, rows, grid, stream); break;
+    case FUSE_BETTER_SCORE: launch_rule<FUSE_BETTER_SCORE>(a, rows, grid, stream); break;
+    case FUSE_ONLY_GOOD_1: launch_rule<FUSE_ONLY_GOOD_1>(a, rows, grid, stream); break;
+    case FUSE_ONLY_GOOD_AVG: launch_rule<FUSE_ONLY_GOOD_AVG>(a, rows, grid, stream); break;
+    case FUSE_OVERLAP: launch_rule<FUSE_OVERLAP>(a, rows, grid, stream); break;
+    case FUSE_BLACK_TO_WHITE: launch_rule<FUSE_BLACK_TO_WHITE>(a, rows, grid, stream); break;
+    case FUSE_GRAD_FILTER: launch_rule<FUSE_GRAD_FILTER>(a, rows, grid, stream); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace d2pc

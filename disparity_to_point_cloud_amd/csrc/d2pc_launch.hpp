@@ -39,6 +39,29 @@ struct MedianArgs {
 bool median_ksize_supported(int k);
 hipError_t launch_median(const void *src, void *dst, const MedianArgs &a, int ksize, hipStream_t stream);
 
+// Depth-map fusion inner loop (d2pc_fusion.hip): rule + combined confidence +
+// 3x3 median + crop.  Rules are numbered as in include/d2pc.h (source order of
+// reference src/depth_map_fusion.cpp:162-235).
+enum {
+  FUSE_WEIGHTED_AVERAGE = 0, FUSE_MAX_DIST = 1, FUSE_MAX_DIST_UNLESS_BLACK = 2, FUSE_BETTER_SCORE = 3,
+  FUSE_ONLY_GOOD_1 = 4, FUSE_ONLY_GOOD_AVG = 5, FUSE_OVERLAP = 6, FUSE_BLACK_TO_WHITE = 7, FUSE_GRAD_FILTER = 8,
+  FUSE_RULE_COUNT = 9
+};
+struct FuseArgs {
+  const uint8_t *in[6] = {};            // depth1, depth2, score1, score2, grad1, grad2 (grads unused without `combined`)
+  uint64_t in_frame_stride[6] = {};
+  uint32_t in_pitch[6] = {};
+  uint8_t *fused = nullptr;             // out_width x out_height
+  uint8_t *combined = nullptr;          // width x height, nullable
+  uint64_t fused_frame_stride = 0, combined_frame_stride = 0;
+  uint32_t fused_pitch = 0, combined_pitch = 0;
+  uint32_t width = 0, height = 0, n_frames = 1;
+  int rule = FUSE_GRAD_FILTER;
+  uint32_t crop_left = 0, crop_top = 0, out_width = 0, out_height = 0;
+  uint32_t strips_x = 0, chunks_y = 0, items = 0;  // filled by launch_fuse
+};
+hipError_t launch_fuse(FuseArgs a, hipStream_t stream, int rows_hint = 0);
+
 bool tile_shape_supported(int pxt);
 uint32_t frame_state_stride(uint32_t tiles_per_frame);
 size_t compact_state_bytes(const Geom &g);

@@ -49,3 +49,42 @@ class DeviceBatch:
             n = int(counts[f])
             out.append((pts[f, :n].copy(), idx[f, :n].copy() if idx is not None else None))
         return out
+
+
+def fuse_planes(ctx: capi.Context, planes, rule=capi.FUSE_GRAD_FILTER, crop=(0, 40, 30, 10), want_combined=True,
+                stream=None):
+    """d2pc_fuse_device on torch uint8 CUDA tensors.
+
+    planes = (depth1, depth2, score1, score2, grad1, grad2), each (H, W) or (F, H, W) with unit
+    column stride (row/frame strides are free, so cropped views work).  Returns (fused, combined or
+    None) as new tensors; asynchronous on `stream` (default: torch's current stream)."""
+    assert len(planes) == 6
+    ref = planes[0]
+    batched = ref.dim() == 3
+    shape = tuple(ref.shape)
+    f, h, w = (shape if batched else (1,) + shape)
+    l, r, t, b = crop
+    desc = capi.fuse_desc_init()
+    desc.rule, desc.width, desc.height, desc.n_frames = rule, w, h, f
+    desc.crop_left, desc.crop_right, desc.crop_top, desc.crop_bottom = l, r, t, b
+    for i, p in enumerate(planes):
+        if p is None:
+            assert i >= 4 and not want_combined
+            continue
+        assert p.is_cuda and p.dtype == torch.uint8 and tuple(p.shape) == shape and p.stride(-1) == 1
+        desc.planes[i] = p.data_ptr()
+        desc.pitch[i] = p.stride(-2)
+        desc.frame_stride[i] = p.stride(0) if batched else 0
+    oh, ow = max(h - t - b, 0), max(w - l - r, 0)
+    fused = torch.empty((f, oh, ow), dtype=torch.uint8, device=ref.device)
+    combined = torch.empty((f, h, w), dtype=torch.uint8, device=ref.device) if want_combined else None
+    desc.fused = fused.data_ptr() if fused.numel() else ref.new_empty(1).data_ptr()
+    desc.fused_pitch, desc.fused_frame_stride = max(ow, 1), max(ow, 1) * oh
+    if want_combined:
+        desc.combined, desc.combined_pitch, desc.combined_frame_stride = combined.data_ptr(), w, w * h
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    ctx.fuse_device(desc, s.cuda_stream)
+    if not batched:
+        fused = fused[0]
+        combined = combined[0] if want_combined else None
+    return fused, combined

@@ -240,6 +240,60 @@ int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames);
  * with compact_algo = 1).  The synchronous entry points check this themselves. */
 int d2pc_check_async_error(d2pc_ctx *ctx);
 
+/*
+ * SURVEY.md section 8(f) #4 -- the inner loop of the sibling node's
+ * DepthMapFusion::publishFusedDepthMap, device-resident and batched:
+ *   per pixel  fused = rule(depth1, depth2, score1, score2, grad1, grad2)
+ *              (src/depth_map_fusion.cpp:115-117,150-160; rules :162-235),
+ *              combined = min(grad1, grad2)                  (:118-121)
+ *   then       cv::medianBlur(fused, fused, 3)               (:124)
+ *   then       cropMat(fused, left, right, top, bottom)      (:130: 0,40,30,10)
+ * in one kernel.  Rules are numbered in the reference's source order;
+ * GRAD_FILTER is the one getFusedDistance calls (:159).  WEIGHTED_AVERAGE
+ * divides by zero in the reference when both scores are non-zero; that case
+ * is defined as 0 here.
+ */
+typedef enum d2pc_fusion_rule {
+  D2PC_FUSE_WEIGHTED_AVERAGE = 0,
+  D2PC_FUSE_MAX_DIST = 1,
+  D2PC_FUSE_MAX_DIST_UNLESS_BLACK = 2,
+  D2PC_FUSE_BETTER_SCORE = 3,
+  D2PC_FUSE_ONLY_GOOD_1 = 4,
+  D2PC_FUSE_ONLY_GOOD_AVG = 5,
+  D2PC_FUSE_OVERLAP = 6,
+  D2PC_FUSE_BLACK_TO_WHITE = 7,
+  D2PC_FUSE_GRAD_FILTER = 8
+} d2pc_fusion_rule;
+
+typedef struct d2pc_fuse_desc {
+  uint32_t struct_size;        /* sizeof(d2pc_fuse_desc) */
+  int32_t rule;                /* d2pc_fusion_rule */
+  int32_t width, height;       /* of every input plane (n x n after cropToSquare in the reference) */
+  int32_t n_frames;            /* independent plane sets, frame_stride apart */
+  int32_t crop_left, crop_right, crop_top, crop_bottom;
+  const void *planes[6];       /* DEVICE: depth1, depth2, score1, score2, grad1, grad2 (8-bit).
+                                  grad1/grad2 may be NULL when `combined` is NULL; planes may alias each
+                                  other (the reference's score1 and grad1 share a buffer, cpp:77) */
+  size_t pitch[6];             /* bytes between rows */
+  size_t frame_stride[6];      /* bytes between frames (ignored when n_frames == 1) */
+  void *fused;                 /* DEVICE out: (width-left-right) x (height-top-bottom) */
+  size_t fused_pitch, fused_frame_stride;
+  void *combined;              /* DEVICE out, nullable: width x height */
+  size_t combined_pitch, combined_frame_stride;
+} d2pc_fuse_desc;
+
+/* struct_size, GRAD_FILTER, n_frames 1, crop 0/40/30/10; everything else zero. */
+void d2pc_fuse_desc_init(d2pc_fuse_desc *desc);
+/* Asynchronous on `stream` (NULL = the HIP default stream).  Outputs must not
+ * overlap the inputs or each other: the reference writes `combined` over
+ * score1 in place (cpp:113), which a caller reproduces by swapping buffers. */
+int d2pc_fuse_device(d2pc_ctx *ctx, const d2pc_fuse_desc *desc, void *stream);
+/* cropToSquare (src/depth_map_fusion.cpp:247-265): the square view of a
+ * cols x rows image, shifted by the offsets.  The side length uses the class
+ * member offset_y_ (cpp:253), the origin the argument: pass both. */
+int d2pc_crop_to_square(int cols, int rows, int offset_x, int offset_y, int member_offset_y,
+                        int *x, int *y, int *n);
+
 /* Launch-shape tuning hook (no counterpart in the reference; results never
  * depend on it).  Keys: "pxt_parity", "pxt_compact" (ROI pixels per thread:
  * 4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by the tile count; 1..4096). */

@@ -25,7 +25,7 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "d2pc_oracle.c")
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("d2pc_oracle.c", "d2pc_oracle.h", "Makefile")
+        for f in ("d2pc_oracle.c", "d2pc_oracle_fusion.c", "d2pc_oracle.h", "Makefile")
     )
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
@@ -58,6 +58,18 @@ def lib():
             ctypes.c_int]
         L.d2pc_oracle_median_u8.restype = None
         L.d2pc_oracle_max_threads.restype = ctypes.c_int
+        L.d2pc_oracle_fuse_pixel.argtypes = [ctypes.c_int] * 7
+        L.d2pc_oracle_fuse_pixel.restype = ctypes.c_int
+        L.d2pc_oracle_fuse.argtypes = [
+            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+            ctypes.c_void_p, ctypes.c_size_t]
+        L.d2pc_oracle_fuse.restype = ctypes.c_int
+        L.d2pc_oracle_crop_to_square.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)]
+        L.d2pc_oracle_crop_to_square.restype = None
+        L.d2pc_oracle_rotate_cw.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_size_t]
+        L.d2pc_oracle_rotate_cw.restype = None
         _lib = L
     return _lib
 
@@ -128,3 +140,48 @@ def median_u8(img: np.ndarray, ksize=11) -> np.ndarray:
 
 def max_threads() -> int:
     return lib().d2pc_oracle_max_threads()
+
+
+# ---- depth-map fusion inner loop (src/depth_map_fusion.cpp:113-130, 150-273) ----
+(FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
+ FUSE_ONLY_GOOD_AVG, FUSE_OVERLAP, FUSE_BLACK_TO_WHITE, FUSE_GRAD_FILTER) = range(9)
+REFERENCE_CROP = (0, 40, 30, 10)  # left, right, top, bottom at cpp:130
+
+
+def fuse_pixel(rule, d1, d2, s1, s2, g1=0, g2=0) -> int:
+    return lib().d2pc_oracle_fuse_pixel(rule, d1, d2, s1, s2, g1, g2)
+
+
+def fuse(planes, rule=FUSE_GRAD_FILTER, crop=REFERENCE_CROP, want_combined=True):
+    """planes = (depth1, depth2, score1, score2, grad1, grad2), equal-shape uint8 images
+    -> (fused (h-t-b, w-l-r), combined (h, w) or None)."""
+    assert len(planes) == 6
+    h, w = planes[0].shape
+    for p in planes:
+        assert p.dtype == np.uint8 and p.shape == (h, w) and p.strides[1] == 1
+    l, r, t, b = crop
+    fused = np.empty((max(h - t - b, 0), max(w - l - r, 0)), dtype=np.uint8)
+    combined = np.empty((h, w), dtype=np.uint8) if want_combined else None
+    ptrs = (ctypes.c_void_p * 6)(*[p.ctypes.data for p in planes])
+    pitch = (ctypes.c_size_t * 6)(*[p.strides[0] for p in planes])
+    st = lib().d2pc_oracle_fuse(ptrs, pitch, w, h, rule, l, r, t, b, fused.ctypes.data, max(fused.strides[0], 1),
+                                combined.ctypes.data if want_combined else None, w)
+    if st != 0:
+        raise ValueError("d2pc_oracle_fuse: bad arguments (%d)" % st)
+    return fused, combined
+
+
+def crop_to_square(cols, rows, offset_x=0, offset_y=0, member_offset_y=None):
+    """-> (x, y, n) of the square region cropToSquare returns (cpp:247-265)."""
+    rect = (ctypes.c_int * 3)()
+    lib().d2pc_oracle_crop_to_square(cols, rows, offset_x, offset_y,
+                                     offset_y if member_offset_y is None else member_offset_y, rect)
+    return tuple(rect)
+
+
+def rotate_cw(img: np.ndarray) -> np.ndarray:
+    assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+    rows, cols = img.shape
+    out = np.empty((cols, rows), dtype=np.uint8)
+    lib().d2pc_oracle_rotate_cw(img.ctypes.data, img.strides[0], cols, rows, out.ctypes.data, out.strides[0])
+    return out

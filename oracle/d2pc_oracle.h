@@ -88,6 +88,33 @@ void d2pc_oracle_median_u8(const uint8_t *src, size_t src_stride_bytes,
                            uint8_t *dst, size_t dst_stride_bytes, int width,
                            int height, int ksize);
 
+/* ---- depth-map fusion inner loop (d2pc_oracle_fusion.c) ---- */
+/* The nine candidate rules of src/depth_map_fusion.cpp:162-235, numbered in
+ * source order; GRAD_FILTER is the one getFusedDistance calls (cpp:159). */
+enum {
+  D2PC_ORACLE_FUSE_WEIGHTED_AVERAGE = 0,
+  D2PC_ORACLE_FUSE_MAX_DIST = 1,
+  D2PC_ORACLE_FUSE_MAX_DIST_UNLESS_BLACK = 2,
+  D2PC_ORACLE_FUSE_BETTER_SCORE = 3,
+  D2PC_ORACLE_FUSE_ONLY_GOOD_1 = 4,
+  D2PC_ORACLE_FUSE_ONLY_GOOD_AVG = 5,
+  D2PC_ORACLE_FUSE_OVERLAP = 6,
+  D2PC_ORACLE_FUSE_BLACK_TO_WHITE = 7,
+  D2PC_ORACLE_FUSE_GRAD_FILTER = 8
+};
+/* One pixel of cpp:150-160 (the int the rule returns, before the store to
+ * unsigned char); -1 for an unknown rule. */
+int d2pc_oracle_fuse_pixel(int rule, int d1, int d2, int s1, int s2, int g1, int g2);
+/* cpp:113-130: planes = {depth1, depth2, score1, score2, grad1, grad2}.
+ * Returns 0, or <0 on bad arguments / allocation failure. */
+int d2pc_oracle_fuse(const uint8_t *const planes[6], const size_t pitch[6], int w, int h, int rule,
+                     int crop_left, int crop_right, int crop_top, int crop_bottom,
+                     uint8_t *fused, size_t fused_pitch, uint8_t *combined, size_t combined_pitch);
+/* cpp:247-265: rect = {x, y, n}. */
+void d2pc_oracle_crop_to_square(int cols, int rows, int offset_x, int offset_y, int member_offset_y, int rect[3]);
+/* cpp:268-273: dst (cols rows of `rows` pixels) = src rotated 90 degrees clockwise. */
+void d2pc_oracle_rotate_cw(const uint8_t *src, size_t src_pitch, int cols, int rows, uint8_t *dst, size_t dst_pitch);
+
 int d2pc_oracle_max_threads(void);
 
 #ifdef __cplusplus

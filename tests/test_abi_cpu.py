@@ -148,3 +148,16 @@ def test_make_q_disparity_image():
     assert lib.d2pc_make_q_disparity_image(0.0, 0.1, 1.0, 1.0, qp) == 1
     assert lib.d2pc_make_q_disparity_image(1.0, -0.1, 1.0, 1.0, qp) == 1
     assert lib.d2pc_set_min_disparity(None, 1.0) == 1
+
+
+def test_crop_to_square_matches_oracle_without_a_gpu():
+    """d2pc_crop_to_square is host arithmetic (cropToSquare, src/depth_map_fusion.cpp:247-265)."""
+    import oracle
+    for cols, rows, ox, oy, my in ((752, 480, -7, 15, 15), (480, 752, 7, -15, 15), (640, 480, 0, 0, 0),
+                                   (480, 640, 0, 0, 0), (100, 100, 3, -4, 4), (100, 100, -3, 4, 4), (65, 33, 1, 1, 1)):
+        assert d2pc.crop_to_square(cols, rows, ox, oy, my) == oracle.crop_to_square(cols, rows, ox, oy, my)
+    with pytest.raises(d2pc.D2pcError):       # the square leaves the image: cv::Mat(Rect) would assert
+        d2pc.crop_to_square(100, 100, 0, 20, 0)   # member offset_y_ stale: n = 100 but x = 10
+    d = d2pc.fuse_desc_init()
+    assert (d.struct_size, d.rule, d.n_frames) == (ctypes.sizeof(d2pc.FuseDesc), d2pc.FUSE_GRAD_FILTER, 1)
+    assert (d.crop_left, d.crop_right, d.crop_top, d.crop_bottom) == (0, 40, 30, 10)   # cpp:130

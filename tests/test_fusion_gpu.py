@@ -1,0 +1,174 @@
+"""GPU tests of d2pc_fuse_device: the fusion rule +
+combined confidence + 3x3 median + crop of the reference's
+src/depth_map_fusion.cpp:113-130, bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+import disparity_to_point_cloud_amd as d2pc
+import oracle
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+from disparity_to_point_cloud_amd.torch_api import fuse_planes  # noqa: E402
+
+
+def _planes(rng, h, w, kind="uniform"):
+    if kind == "uniform":
+        return [rng.integers(0, 256, size=(h, w)).astype(np.uint8) for _ in range(6)]
+    # reference-like: smooth-ish depths with black holes, scores near the thresholds 100/125, depths near 230
+    d1 = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    d2 = np.clip(d1.astype(np.int32) + rng.integers(-40, 41, size=(h, w)), 0, 255).astype(np.uint8)
+    d1[rng.random((h, w)) < 0.1] = 0
+    d2[rng.random((h, w)) < 0.1] = 0
+    s1 = rng.choice(np.array([0, 1, 19, 20, 49, 50, 99, 100, 101, 124, 125, 126, 255], dtype=np.uint8), size=(h, w))
+    s2 = rng.choice(np.array([0, 1, 19, 20, 49, 50, 99, 100, 101, 124, 125, 126, 255], dtype=np.uint8), size=(h, w))
+    g1 = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    g2 = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    return [d1, d2, s1, s2, g1, g2]
+
+
+def _gpu(ctx, planes, **kw):
+    dev = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes]
+    fused, comb = fuse_planes(ctx, dev, **kw)
+    torch.cuda.synchronize()
+    return fused.cpu().numpy(), None if comb is None else comb.cpu().numpy()
+
+
+@pytest.mark.parametrize("rule", range(9))
+def test_rule_table_exhaustive_over_distances(rule):
+    """Every (dist1, dist2) pair x the scores around every threshold, no median/crop effects:
+    a 3x3-constant image makes the median the identity."""
+    scores = np.array([0, 1, 2, 19, 20, 21, 49, 50, 99, 100, 101, 124, 125, 126, 229, 230, 255], dtype=np.uint8)
+    d = np.arange(256, dtype=np.uint8)
+    d1, d2 = np.meshgrid(d, d, indexing="ij")                      # 256 x 256 pairs
+    d1 = np.repeat(np.repeat(d1, 3, axis=0), 3, axis=1)            # 768 x 768, constant 3x3 cells
+    d2 = np.repeat(np.repeat(d2, 3, axis=0), 3, axis=1)
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        for s1 in scores:
+            for s2 in scores[::2] if rule != d2pc.FUSE_GRAD_FILTER else scores:
+                planes = [d1, d2, np.full_like(d1, s1), np.full_like(d1, s2), d1, d2]
+                got, _ = _gpu(ctx, planes, rule=rule, crop=(0, 0, 0, 0), want_combined=False)
+                centre = got[1::3, 1::3]                           # centre of each cell: median of 9 equal values
+                want = np.array([[oracle.fuse_pixel(rule, int(a), int(b), int(s1), int(s2)) & 0xFF
+                                  for b in (0, 1, 4, 5, 100, 229, 230, 255)] for a in range(256)], dtype=np.uint8)
+                assert np.array_equal(centre[:, [0, 1, 4, 5, 100, 229, 230, 255]], want), (rule, s1, s2)
+        # and one full 65536-pair table per rule through the oracle's own image path
+        planes = [d1, d2, np.full_like(d1, 110), np.full_like(d1, 110), d1, d2]
+        got, _ = _gpu(ctx, planes, rule=rule, crop=(0, 0, 0, 0), want_combined=False)
+        want, _ = oracle.fuse(planes, rule=rule, crop=(0, 0, 0, 0), want_combined=False)
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("w,h", [(465, 465), (480, 480), (248, 8), (249, 9), (247, 7), (496, 16), (497, 17), (1, 1),
+                                 (2, 3), (3, 2), (4, 4), (5, 1), (1, 5), (61, 83), (752, 480), (1000, 50)])
+@pytest.mark.parametrize("kind", ["uniform", "thresholds"])
+def test_fuse_matches_oracle_no_crop(w, h, kind):
+    rng = np.random.default_rng(w * 7919 + h + len(kind))
+    planes = _planes(rng, h, w, kind)
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        fused, comb = _gpu(ctx, planes, crop=(0, 0, 0, 0))
+    want_f, want_c = oracle.fuse(planes, crop=(0, 0, 0, 0))
+    assert np.array_equal(comb, want_c)
+    assert np.array_equal(fused, want_f)
+
+
+@pytest.mark.parametrize("crop", [(0, 40, 30, 10), (1, 2, 3, 4), (40, 0, 10, 30), (5, 5, 0, 0), (0, 0, 7, 9),
+                                  (100, 100, 0, 0), (0, 465, 0, 0), (0, 0, 465, 0), (232, 233, 232, 233)])
+def test_reference_crop_and_others(crop):
+    rng = np.random.default_rng(sum(crop))
+    planes = _planes(rng, 465, 465, "thresholds")
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        fused, comb = _gpu(ctx, planes, crop=crop)
+    want_f, want_c = oracle.fuse(planes, crop=crop)
+    assert fused.shape == want_f.shape
+    assert np.array_equal(fused, want_f)
+    assert np.array_equal(comb, want_c)
+
+
+def test_batched_views_with_pitches_and_aliasing():
+    """Planes are crop-to-square VIEWS of larger images (odd byte offsets, pitch != width), batched,
+    and score1 aliases grad1 as in the reference (cpp:77)."""
+    rng = np.random.default_rng(5)
+    F, H, W = 3, 480, 752
+    big = [torch.from_numpy(rng.integers(0, 256, size=(F, H, W)).astype(np.uint8)).cuda() for _ in range(5)]
+    x1, y1, n = d2pc.crop_to_square(W, H, -7, 15)
+    x2, y2, n2 = d2pc.crop_to_square(W, H, 7, -15, 15)
+    assert n == n2 == 465 and (x1, y1) == oracle.crop_to_square(W, H, -7, 15)[:2]
+    v = lambda t, x, y: t[:, y:y + n, x:x + n]  # noqa: E731
+    d1, s1 = v(big[0], x1, y1), v(big[2], x1, y1)
+    d2_, s2 = v(big[1], x2, y2), v(big[3], x2, y2)
+    g2 = v(big[4], x2, y2)
+    planes = [d1, d2_, s1, s2, s1, g2]  # grad1 IS score1
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        fused, comb = fuse_planes(ctx, planes)
+        torch.cuda.synchronize()
+    for f in range(F):
+        host = [np.ascontiguousarray(p[f].cpu().numpy()) for p in planes]
+        want_f, want_c = oracle.fuse(host)
+        assert np.array_equal(fused[f].cpu().numpy(), want_f)
+        assert np.array_equal(comb[f].cpu().numpy(), want_c)
+
+
+def test_large_batch_takes_the_tall_strip_kernel():
+    rng = np.random.default_rng(11)
+    F, H, W = 4, 2160, 2160  # 9 strips x 135 chunks x 4 = 4860 < 8192 -> 8-row kernel
+    planes8 = [rng.integers(0, 256, size=(1, 300, 500)).astype(np.uint8) for _ in range(6)]
+    planes16 = [np.broadcast_to(rng.integers(0, 256, size=(1, H, W)).astype(np.uint8), (F, H, W)).copy()
+                for _ in range(6)]
+    planes16 = [np.concatenate([p, p], axis=0) for p in planes16]  # 8 frames -> 9720 items -> 16-row kernel
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        for planes in (planes8, planes16):
+            fused, comb = _gpu(ctx, planes)
+            want_f, want_c = oracle.fuse([p[0] for p in planes])
+            for f in range(planes[0].shape[0]):
+                assert np.array_equal(fused[f], want_f)
+                assert np.array_equal(comb[f], want_c)
+
+
+def test_without_combined_grads_may_be_null():
+    rng = np.random.default_rng(3)
+    planes = _planes(rng, 100, 120)
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        dev = [torch.from_numpy(p).cuda() for p in planes[:4]] + [None, None]
+        fused, comb = fuse_planes(ctx, dev, want_combined=False)
+        torch.cuda.synchronize()
+    assert comb is None
+    assert np.array_equal(fused.cpu().numpy(), oracle.fuse(planes, want_combined=False)[0])
+
+
+def test_rejects_bad_arguments():
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        x = [torch.zeros((64, 64), dtype=torch.uint8, device="cuda") for _ in range(6)]
+        out = torch.zeros((64, 64), dtype=torch.uint8, device="cuda")
+        comb = torch.zeros((64, 64), dtype=torch.uint8, device="cuda")
+
+        def desc(**kw):
+            d = d2pc.fuse_desc_init()
+            d.width = d.height = 64
+            d.crop_left = d.crop_right = d.crop_top = d.crop_bottom = 0
+            for i in range(6):
+                d.planes[i], d.pitch[i] = x[i].data_ptr(), 64
+            d.fused, d.fused_pitch = out.data_ptr(), 64
+            d.combined, d.combined_pitch = comb.data_ptr(), 64
+            for k, v in kw.items():
+                setattr(d, k, v)
+            return d
+
+        ctx.fuse_device(desc())  # the base descriptor is fine
+        for bad, status in ((dict(rule=9), 1), (dict(rule=-1), 1), (dict(width=0), 3), (dict(n_frames=0), 3),
+                            (dict(crop_left=65), 3), (dict(crop_top=60, crop_bottom=5), 3), (dict(fused=None), 1),
+                            (dict(fused_pitch=63), 3), (dict(combined_pitch=10), 3), (dict(struct_size=8), 1),
+                            (dict(fused=x[2].data_ptr()), 1), (dict(combined=x[0].data_ptr()), 1),
+                            (dict(combined=out.data_ptr()), 1)):
+            with pytest.raises(d2pc.D2pcError) as e:
+                ctx.fuse_device(desc(**bad))
+            assert e.value.status == status, bad
+        d = desc()
+        d.planes[1] = None
+        with pytest.raises(d2pc.D2pcError):
+            ctx.fuse_device(d)
+        d = desc()
+        d.pitch[3] = 10
+        with pytest.raises(d2pc.D2pcError):
+            ctx.fuse_device(d)
+        torch.cuda.synchronize()

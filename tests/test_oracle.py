@@ -204,3 +204,86 @@ def test_median_u8_against_numpy():
         win = np.lib.stride_tricks.sliding_window_view(pad, (k, k)).reshape(40, 57, k * k)
         ref = np.sort(win, axis=-1)[..., (k * k) // 2]
         assert np.array_equal(oracle.median_u8(img, k), ref)
+
+
+# ---- depth-map fusion inner loop ---------------------------
+def test_fusion_rules_hand_derived():
+    """Answers worked out by hand from the text of src/depth_map_fusion.cpp:162-235."""
+    G = oracle.FUSE_GRAD_FILTER
+    assert oracle.fuse_pixel(G, 50, 60, 10, 20) == 50          # score1 better, < 100, dist1 < 230
+    assert oracle.fuse_pixel(G, 50, 60, 20, 10) == 60          # score2 better
+    assert oracle.fuse_pixel(G, 230, 60, 10, 20) == 0          # dist1 too close, ratio 3.8 -> 0
+    assert oracle.fuse_pixel(G, 229, 200, 10, 20) == 229
+    assert oracle.fuse_pixel(G, 100, 100, 110, 110) == 100     # equal scores -> third branch, averaged
+    assert oracle.fuse_pixel(G, 100, 101, 124, 124) == 100     # float(201)/2.0 = 100.5 -> int 100
+    assert oracle.fuse_pixel(G, 100, 101, 125, 110) == 0       # score1 !< 125
+    assert oracle.fuse_pixel(G, 80, 100, 110, 110) == 90       # float(0.8f) > 0.8 (double): the exact ratio 4/5 passes
+    assert oracle.fuse_pixel(G, 100, 80, 110, 110) == 0        # 1.25 is exact in float: 5/4 fails
+    assert oracle.fuse_pixel(G, 0, 0, 110, 110) == 0           # NaN compares false
+    assert oracle.fuse_pixel(G, 7, 0, 110, 110) == 0           # +inf fails the upper bound
+    assert oracle.fuse_pixel(G, 100, 90, 99, 99) == 95         # equal scores below thres still average
+    W = oracle.FUSE_WEIGHTED_AVERAGE                           # int weights: 1 iff score == 0
+    assert oracle.fuse_pixel(W, 10, 21, 0, 0) == 15
+    assert oracle.fuse_pixel(W, 10, 21, 0, 1) == 10
+    assert oracle.fuse_pixel(W, 10, 21, 5, 0) == 21
+    assert oracle.fuse_pixel(W, 10, 21, 1, 1) == 0             # 0/0 in the reference: defined as 0
+    assert oracle.fuse_pixel(oracle.FUSE_MAX_DIST, 10, 21, 0, 0) == 10
+    assert oracle.fuse_pixel(oracle.FUSE_MAX_DIST_UNLESS_BLACK, 0, 21, 0, 0) == 21
+    assert oracle.fuse_pixel(oracle.FUSE_MAX_DIST_UNLESS_BLACK, 30, 21, 0, 0) == 21
+    assert oracle.fuse_pixel(oracle.FUSE_BETTER_SCORE, 1, 2, 5, 5) == 2
+    assert oracle.fuse_pixel(oracle.FUSE_BETTER_SCORE, 1, 2, 4, 5) == 1
+    assert oracle.fuse_pixel(oracle.FUSE_ONLY_GOOD_1, 1, 2, 0, 49) == 2
+    assert oracle.fuse_pixel(oracle.FUSE_ONLY_GOOD_1, 1, 2, 0, 50) == 0
+    assert oracle.fuse_pixel(oracle.FUSE_ONLY_GOOD_AVG, 255, 254, 99, 99) == 254
+    assert oracle.fuse_pixel(oracle.FUSE_ONLY_GOOD_AVG, 255, 254, 100, 99) == 0
+    assert oracle.fuse_pixel(oracle.FUSE_OVERLAP, 1, 2, 19, 20) == 150
+    assert oracle.fuse_pixel(oracle.FUSE_OVERLAP, 1, 2, 20, 19) == 255
+    assert oracle.fuse_pixel(oracle.FUSE_OVERLAP, 1, 2, 19, 19) == 0
+    assert oracle.fuse_pixel(oracle.FUSE_BLACK_TO_WHITE, 1, 2, 55, 0) == 200
+    assert oracle.fuse_pixel(99, 1, 2, 3, 4) == -1
+
+
+def test_fusion_grad_filter_integer_form_is_exhaustively_equal():
+    """The device evaluates cpp:224-232 in integers; check that form against the literal one for all inputs
+    the ratio test can see (every distance pair, scores either side of each threshold)."""
+    d1, d2 = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    for s1, s2 in ((110, 110), (99, 99), (124, 125), (10, 10)):
+        lit = np.array([[oracle.fuse_pixel(oracle.FUSE_GRAD_FILTER, a, b, s1, s2) for b in range(256)]
+                        for a in range(256)])
+        ok = (5 * d1 >= 4 * d2) & (4 * d1 < 5 * d2) & (s1 < 125) & (s2 < 125)
+        assert np.array_equal(lit, np.where(ok, (d1 + d2) >> 1, 0))
+
+
+def test_fusion_image_path_median_and_crop():
+    # a constant pair of planes: every rule output is constant, the median keeps it, the crop only sizes it
+    planes = [np.full((50, 60), v, dtype=np.uint8) for v in (100, 101, 124, 124, 7, 9)]
+    fused, comb = oracle.fuse(planes)
+    assert fused.shape == (50 - 30 - 10, 60 - 40) and (fused == 100).all()
+    assert comb.shape == (50, 60) and (comb == 7).all()
+    # a single outlier is removed by the 3x3 median, a 2x2 block at the corner survives by replication
+    d = np.full((40, 45), 50, dtype=np.uint8)
+    d[20, 20] = 200
+    d[0:2, 0:2] = 90
+    z = np.zeros_like(d)
+    planes = [d, d, z, z + 1, z, z]           # score1 < score2 -> dist1
+    fused, _ = oracle.fuse(planes, crop=(0, 0, 0, 0), want_combined=False)
+    assert fused[20, 20] == 50 and fused[0, 0] == 90 and fused[1, 1] == 50 and fused[0, 1] == 90
+    want = oracle.median_u8(d, 3)
+    assert np.array_equal(fused, want)
+    fused_c, _ = oracle.fuse(planes, crop=(3, 4, 5, 6), want_combined=False)
+    assert np.array_equal(fused_c, want[5:40 - 6, 3:45 - 4])
+    with pytest.raises(ValueError):
+        oracle.fuse(planes, crop=(30, 30, 0, 0))
+
+
+def test_crop_to_square_and_rotate():
+    # launch/depth_map_fusion.launch: offset_x -7, offset_y 15 on the 752x480 camera image
+    assert oracle.crop_to_square(752, 480, -7, 15) == (133, 15, 465)        # landscape: x = -7 + (745-465)/2
+    # DisparityCb2 rotates first (480 wide, 752 high) and passes the NEGATED offsets (cpp:57)
+    assert oracle.crop_to_square(480, 752, 7, -15, 15) == (7, 117, 465)     # portrait: y = -15 + (737-473)/2
+    assert oracle.crop_to_square(640, 480) == (80, 0, 480)
+    assert oracle.crop_to_square(480, 640) == (0, 80, 480)
+    a = np.arange(6, dtype=np.uint8).reshape(2, 3)
+    assert np.array_equal(oracle.rotate_cw(a), np.array([[3, 0], [4, 1], [5, 2]], dtype=np.uint8))
+    img = np.random.default_rng(1).integers(0, 256, size=(37, 91)).astype(np.uint8)
+    assert np.array_equal(oracle.rotate_cw(img), np.rot90(img, -1))
