@@ -53,7 +53,7 @@ struct d2pc_ctx {
   int last_compact_algo = 0;  // what the last COMPACT launch used
   int force_general_q = 0;
   int no_vec_rows = 0;
-  int fuse_rows = 0;             // d2pc_fuse_device rows per wave: 0 = choose, else 4/8/16
+  int fuse_rows = 0;             // d2pc_fuse_device rows per wave: 0 = choose, else 2..1024
   // device scratch
   void *d_state = nullptr;   size_t state_cap = 0;
   void *d_in = nullptr;      size_t in_cap = 0;
@@ -522,7 +522,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 1 && value <= 64) ctx->onepass_blocks_per_cu = value;
   else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
-  else if (!strcmp(key, "fuse_rows") && (value == 0 || value == 4 || value == 8 || value == 16)) ctx->fuse_rows = value;
+  else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
   return D2PC_OK;
 }

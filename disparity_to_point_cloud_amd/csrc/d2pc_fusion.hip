@@ -31,6 +31,10 @@ namespace d2pc {
 namespace {
 
 constexpr int kStripCols = 248;  // output columns per wave: 62 lanes x 4 pixels
+#ifndef D2PC_FUSE_BLOCK
+#define D2PC_FUSE_BLOCK 256
+#endif
+constexpr int kFuseBlock = D2PC_FUSE_BLOCK;  // waves of a block take horizontally adjacent strips
 
 // ---- two 16-bit fields per dword -------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -39,6 +43,12 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk(uint32_t c) { return c | (c << 16); }  // both fields = c
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {         // per-field a - b (wraps)
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {         // per-field a + b (wraps)
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_shl2(uint32_t a) {                    // per-field a << 2
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) << 2);
 }
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
@@ -92,25 +102,6 @@ __device__ __forceinline__ LaneCols lane_cols(int x, int w) {
   c.selO = sel[1] | (kZero << 8) | (sel[3] << 16) | (kZero << 24);
   return c;
 }
-struct Px4 {
-  uint32_t e, o;  // pixels (0,2) and (1,3), one 16-bit field each
-};
-// `row` is wave-uniform (scalar base + 32-bit lane offset addressing).
-template <bool NARROW>
-__device__ __forceinline__ Px4 load_px4(const uint8_t *__restrict__ row, const LaneCols &c) {
-  Px4 r;
-  if (!NARROW) {
-    uint32_t v;
-    __builtin_memcpy(&v, row + c.col, 4);
-    r.e = __builtin_amdgcn_perm(v, v, c.selE);
-    r.o = __builtin_amdgcn_perm(v, v, c.selO);
-  } else {
-    r.e = uint32_t(row[c.xs[0]]) | (uint32_t(row[c.xs[2]]) << 16);
-    r.o = uint32_t(row[c.xs[1]]) | (uint32_t(row[c.xs[3]]) << 16);
-  }
-  return r;
-}
-
 // The selected rule (reference src/depth_map_fusion.cpp:162-235) on a pair of
 // pixels; every operand field holds an 8-bit value.  lt(a, b) below is "the
 // sign bit of a - b", valid while |a - b| < 2^15.
@@ -144,9 +135,9 @@ __device__ __forceinline__ uint32_t fuse_pair(uint32_t d1, uint32_t d2, uint32_t
     default: {  // FUSE_GRAD_FILTER
       const uint32_t a = pk_sign_mask(pk_sub(s1, s2) & pk_sub(s1, pk(100)) & pk_sub(d1, pk(230)));
       const uint32_t b = pk_sign_mask(pk_sub(s2, s1) & pk_sub(s2, pk(100)) & pk_sub(d2, pk(230)));
-      const uint32_t d1x4 = d1 << 2, d2x4 = d2 << 2;
-      const uint32_t c = pk_sign_mask(~pk_sub(d1x4 + d1, d2x4) & pk_sub(d1x4, d2x4 + d2) & pk_sub(s1, pk(125)) &
-                                      pk_sub(s2, pk(125)));
+      // 5*d1 >= 4*d2 && 4*d1 < 5*d2  <=>  t + d1 >= 0 && t - d2 < 0  with  t = 4*(d1 - d2)
+      const uint32_t t = pk_shl2(pk_sub(d1, d2));
+      const uint32_t c = pk_sign_mask(~pk_add(t, d1) & pk_sub(t, d2) & pk_sub(s1, pk(125)) & pk_sub(s2, pk(125)));
       return pick(a, d1, pick(b, d2, c & avg));
     }
   }
@@ -165,71 +156,108 @@ __device__ __forceinline__ void store_px4(uint8_t *__restrict__ dst_row, int x, 
 
 }  // namespace
 
-// One kernel per rule: with the rule as a run-time switch the unrolled body
-// outgrows the instruction cache.  NARROW = images less than 4 pixels wide.
-#ifndef D2PC_FUSE_WAVES_PER_EU
-#define D2PC_FUSE_WAVES_PER_EU 2
-#endif
-template <int RULE, int R, bool NARROW>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(D2PC_FUSE_WAVES_PER_EU)))
-void k_fuse_median3(const FuseArgs a) {
+// Raw dwords of one image row for one lane.
+struct RowRaw {
+  uint32_t d1, d2, s1, s2, g1, g2;
+};
+
+// One kernel per rule (a run-time rule switch in the inner loop would be paid
+// per pixel pair).  NARROW = images less than 4 pixels wide.
+//
+// A wave walks down its strip two rows per step, holding a rolling window of
+// fused rows: with S0,S1 = rows k,k+1 already fused and N2,N3 = rows k+2,k+3
+// new, the sorted pair (S1,N2) serves BOTH outputs of the step (rows k+1 and
+// k+2 take S0 resp. N3 as the third value), and the raw loads of the next step
+// are issued before this step's arithmetic.  Only the first row of a strip is
+// fused twice (by this wave and the one above), so strips can be tall without
+// costing registers.
+template <int RULE, bool NARROW>
+__global__ __launch_bounds__(kFuseBlock) void k_fuse_median3(const FuseArgs a) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t item = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // A block is four horizontally adjacent strips of one chunk (1 KB of every row: measured 12-15 %
+  // faster than four vertically adjacent chunks of one strip, despite the latter's shared halo rows).
+  // The divisions run on the VALU; readfirstlane puts the (uniform) results back into SGPRs so that
+  // every row pointer below is a scalar base.
+  const uint32_t item = blockIdx.x * (kFuseBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (item >= a.items) return;  // wave-uniform
-  // the divisions run on the VALU; readfirstlane puts the (uniform) results back into SGPRs so that
-  // every row pointer below is a scalar base
   const uint32_t rest = __builtin_amdgcn_readfirstlane(item / a.strips_x);
   const uint32_t strip = item - rest * a.strips_x;
   const uint32_t frame = __builtin_amdgcn_readfirstlane(rest / a.chunks_y);
   const uint32_t chunk = rest - frame * a.chunks_y;
   const int w = int(a.width), h = int(a.height);
-  const int x0 = int(strip) * kStripCols, y0 = int(chunk) * R;
+  const int x0 = int(strip) * kStripCols, y0 = int(chunk * a.rows_per_wave);
+  const int rows = min(int(a.rows_per_wave), h - y0);  // >= 1
   const int x = x0 - 4 + int(lane) * 4;  // lane 0 = left halo, lane 63 = right halo
   const LaneCols lc = lane_cols(x, w);
 
   const uint8_t *pl[6];
 #pragma unroll
   for (int p = 0; p < 6; ++p) pl[p] = a.in[p] + uint64_t(frame) * a.in_frame_stride[p];
-
   const bool owner = lane >= 1u && lane <= 62u && x < w;  // halo lanes store nothing
   uint8_t *cf = a.combined ? a.combined + uint64_t(frame) * a.combined_frame_stride : nullptr;
-
-  // ---- fused value of rows y0-1 .. y0+R (replicated at the image border), as
-  //      pairs: E = pixels (0,2), O = pixels (1,3) of the lane; the combined
-  //      confidence min(grad1, grad2) (cpp:118-121) of the strip's own rows goes
-  //      out on the way so that its loads overlap the rule arithmetic ----------
-  uint32_t selE[R + 2], selO[R + 2];
-#pragma unroll
-  for (int i = 0; i < R + 2; ++i) {
-    const int yu = y0 - 1 + i;
-    const int y = yu < 0 ? 0 : yu >= h ? h - 1 : yu;
-    const Px4 d1 = load_px4<NARROW>(pl[0] + uint32_t(y) * a.in_pitch[0], lc);  // plane extents < 4 GiB (host-checked)
-    const Px4 d2 = load_px4<NARROW>(pl[1] + uint32_t(y) * a.in_pitch[1], lc);
-    const Px4 s1 = load_px4<NARROW>(pl[2] + uint32_t(y) * a.in_pitch[2], lc);
-    const Px4 s2 = load_px4<NARROW>(pl[3] + uint32_t(y) * a.in_pitch[3], lc);
-    if (cf && i >= 1 && i <= R) {  // wave-uniform
-      const Px4 g1 = load_px4<NARROW>(pl[4] + uint32_t(y) * a.in_pitch[4], lc);
-      const Px4 g2 = load_px4<NARROW>(pl[5] + uint32_t(y) * a.in_pitch[5], lc);
-      const uint32_t m = pk_min(g1.e, g2.e) | (pk_min(g1.o, g2.o) << 8);
-      if (owner && yu < h) store_px4(cf + uint32_t(y) * a.combined_pitch, x, 0, w, m);
-    }
-    selE[i] = fuse_pair<RULE>(d1.e, d2.e, s1.e, s2.e);
-    selO[i] = fuse_pair<RULE>(d1.o, d2.o, s1.o, s2.o);
-  }
-
-  // ---- 3x3 median of the fused image, cropped store (cpp:124,130) -------------
   uint8_t *ff = a.fused + uint64_t(frame) * a.fused_frame_stride;
   const int cx0 = int(a.crop_left), cx1 = cx0 + int(a.out_width);
   const int cy0 = int(a.crop_top), cy1 = cy0 + int(a.out_height);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
+
+  // window row k <-> image row y0 - 1 + k, replicated at the image border
+  auto fetch = [&](int k) {
+    const int y = min(max(y0 - 1 + k, 0), h - 1);
+    // Opaque copy of the (loop-invariant) lane column: otherwise LLVM hoists plane + column into a
+    // 64-bit VGPR pair and pays a 64-bit vector add per load; this way every load is
+    // "scalar row base + 32-bit lane offset" and costs no VALU work.
+    uint32_t col = lc.col;
+    asm volatile("" : "+v"(col));
+    RowRaw r;
+    __builtin_memcpy(&r.d1, (pl[0] + uint32_t(y) * a.in_pitch[0]) + col, 4);  // plane extents < 4 GiB (host-checked)
+    __builtin_memcpy(&r.d2, (pl[1] + uint32_t(y) * a.in_pitch[1]) + col, 4);
+    __builtin_memcpy(&r.s1, (pl[2] + uint32_t(y) * a.in_pitch[2]) + col, 4);
+    __builtin_memcpy(&r.s2, (pl[3] + uint32_t(y) * a.in_pitch[3]) + col, 4);
+    r.g1 = r.g2 = 0;
+    if (cf) {  // launch-uniform
+      __builtin_memcpy(&r.g1, (pl[4] + uint32_t(y) * a.in_pitch[4]) + col, 4);
+      __builtin_memcpy(&r.g2, (pl[5] + uint32_t(y) * a.in_pitch[5]) + col, 4);
+    }
+    return r;
+  };
+  auto fetch_narrow = [&](int k) {  // w < 4: gather the clamped columns
+    const int y = min(max(y0 - 1 + k, 0), h - 1);
+    auto gather = [&](int p) {
+      const uint8_t *row = pl[p] + uint32_t(y) * a.in_pitch[p];
+      return uint32_t(row[lc.xs[0]]) | (uint32_t(row[lc.xs[1]]) << 8) | (uint32_t(row[lc.xs[2]]) << 16) |
+             (uint32_t(row[lc.xs[3]]) << 24);
+    };
+    RowRaw r;
+    r.d1 = gather(0), r.d2 = gather(1), r.s1 = gather(2), r.s2 = gather(3);
+    r.g1 = r.g2 = 0;
+    if (cf) r.g1 = gather(4), r.g2 = gather(5);
+    return r;
+  };
+  auto get = [&](int k) { return NARROW ? fetch_narrow(k) : fetch(k); };
+  const uint32_t selE = NARROW ? 0x0c020c00u : lc.selE, selO = NARROW ? 0x0c030c01u : lc.selO;
+
+  struct Pair2 {
+    uint32_t e, o;
+  };
+  // fused row (and, for the strip's own rows, the combined confidence of cpp:118-121)
+  auto fuse_row = [&](const RowRaw &r, int k) {
+    Pair2 f;
+    f.e = fuse_pair<RULE>(__builtin_amdgcn_perm(r.d1, r.d1, selE), __builtin_amdgcn_perm(r.d2, r.d2, selE),
+                          __builtin_amdgcn_perm(r.s1, r.s1, selE), __builtin_amdgcn_perm(r.s2, r.s2, selE));
+    f.o = fuse_pair<RULE>(__builtin_amdgcn_perm(r.d1, r.d1, selO), __builtin_amdgcn_perm(r.d2, r.d2, selO),
+                          __builtin_amdgcn_perm(r.s1, r.s1, selO), __builtin_amdgcn_perm(r.s2, r.s2, selO));
+    if (cf && k >= 1 && k <= rows) {  // wave-uniform
+      const uint32_t m = pk_min(__builtin_amdgcn_perm(r.g1, r.g1, selE), __builtin_amdgcn_perm(r.g2, r.g2, selE)) |
+                         (pk_min(__builtin_amdgcn_perm(r.g1, r.g1, selO), __builtin_amdgcn_perm(r.g2, r.g2, selO)) << 8);
+      const int y = y0 - 1 + k;
+      if (owner) store_px4(cf + uint32_t(y) * a.combined_pitch, x, 0, w, m);
+    }
+    return f;
+  };
+  // median of output row j (image row y0 + j) from the sorted pair (mn, mx) of its two other rows and c
+  auto emit = [&](int j, uint32_t mnE, uint32_t mxE, uint32_t mnO, uint32_t mxO, const Pair2 &c) {
     // sorted vertical triples of the lane's columns: E = columns (0,2), O = (1,3)
-    const uint32_t mnE = pk_min(selE[r], selE[r + 1]), mxE = pk_max(selE[r], selE[r + 1]);
-    const uint32_t mnO = pk_min(selO[r], selO[r + 1]), mxO = pk_max(selO[r], selO[r + 1]);
-    const uint32_t loE = pk_min(mnE, selE[r + 2]), hiE = pk_max(mxE, selE[r + 2]);
-    const uint32_t meE = pk_max(mnE, pk_min(mxE, selE[r + 2]));
-    const uint32_t loO = pk_min(mnO, selO[r + 2]), hiO = pk_max(mxO, selO[r + 2]);
-    const uint32_t meO = pk_max(mnO, pk_min(mxO, selO[r + 2]));
+    const uint32_t loE = pk_min(mnE, c.e), hiE = pk_max(mxE, c.e), meE = pk_max(mnE, pk_min(mxE, c.e));
+    const uint32_t loO = pk_min(mnO, c.o), hiO = pk_max(mxO, c.o), meO = pk_max(mnO, pk_min(mxO, c.o));
     // columns (-1,1) and (2,4): column -1 is the left lane's column 3, column 4 the right lane's column 0
     const uint32_t loL = __builtin_amdgcn_alignbit(loO, from_left_lane(loO), 16);
     const uint32_t meL = __builtin_amdgcn_alignbit(meO, from_left_lane(meO), 16);
@@ -237,52 +265,87 @@ void k_fuse_median3(const FuseArgs a) {
     const uint32_t loR = __builtin_amdgcn_alignbit(from_right_lane(loE), loE, 16);
     const uint32_t meR = __builtin_amdgcn_alignbit(from_right_lane(meE), meE, 16);
     const uint32_t hiR = __builtin_amdgcn_alignbit(from_right_lane(hiE), hiE, 16);
-    // outputs (0,2) see columns L,E,O; outputs (1,3) see columns E,O,R
-    const uint32_t outE = pk_med3(pk_max(pk_max(loL, loE), loO), pk_med3(meL, meE, meO), pk_min(pk_min(hiL, hiE), hiO));
-    const uint32_t outO = pk_med3(pk_max(pk_max(loE, loO), loR), pk_med3(meE, meO, meR), pk_min(pk_min(hiE, hiO), hiR));
-    const int y = y0 + r;
-    if (owner && y >= cy0 && y < cy1) store_px4(ff + uint32_t(y - cy0) * a.fused_pitch, x, cx0, cx1, outE | (outO << 8));
+    // outputs (0,2) see columns L,E,O; outputs (1,3) see columns E,O,R: the E,O part is shared
+    const uint32_t loEO = pk_max(loE, loO), hiEO = pk_min(hiE, hiO);
+    const uint32_t meMn = pk_min(meE, meO), meMx = pk_max(meE, meO);
+    const uint32_t outE = pk_med3(pk_max(loL, loEO), pk_max(meMn, pk_min(meMx, meL)), pk_min(hiL, hiEO));
+    const uint32_t outO = pk_med3(pk_max(loR, loEO), pk_max(meMn, pk_min(meMx, meR)), pk_min(hiR, hiEO));
+    const int y = y0 + j;
+    if (owner && j < rows && y >= cy0 && y < cy1)
+      store_px4(ff + uint32_t(y - cy0) * a.fused_pitch, x, cx0, cx1, outE | (outO << 8));
+  };
+
+  // two steps per trip, the raw rows alternating between two register sets (no window copies)
+  auto step = [&](int k, const RowRaw &c2, const RowRaw &c3, Pair2 &s0, Pair2 &s1) {
+    const Pair2 f2 = fuse_row(c2, k + 2), f3 = fuse_row(c3, k + 3);
+    const uint32_t mnE = pk_min(s1.e, f2.e), mxE = pk_max(s1.e, f2.e);
+    const uint32_t mnO = pk_min(s1.o, f2.o), mxO = pk_max(s1.o, f2.o);
+    emit(k, mnE, mxE, mnO, mxO, s0);
+    emit(k + 1, mnE, mxE, mnO, mxO, f3);
+    s0 = f2;
+    s1 = f3;
+  };
+  Pair2 s0, s1;
+  {
+    const RowRaw r0 = get(0), r1 = get(1);
+    s0 = fuse_row(r0, 0);
+    s1 = fuse_row(r1, 1);
+  }
+  RowRaw a2 = get(2), a3 = get(3), b2 = a2, b3 = a3;
+  for (int k = 0; k < rows; k += 4) {  // outputs k .. k+3 from window rows k .. k+5
+    if (k + 2 < rows) {  // the next step's rows are in flight during this step's arithmetic
+      b2 = get(k + 4);
+      b3 = get(k + 5);
+    }
+    step(k, a2, a3, s0, s1);
+    if (k + 2 >= rows) break;
+    if (k + 4 < rows) {
+      a2 = get(k + 6);
+      a3 = get(k + 7);
+    }
+    step(k + 2, b2, b3, s0, s1);
   }
 }
 
 namespace {
 template <int RULE>
-void launch_rule(const FuseArgs &a, uint32_t rows, uint32_t grid, hipStream_t stream) {
+void launch_rule(const FuseArgs &a, uint32_t grid, hipStream_t stream) {
   if (a.width < 4)
-    hipLaunchKernelGGL((k_fuse_median3<RULE, 8, true>), dim3(grid), dim3(kBlock), 0, stream, a);
-  else if (rows == 16)
-    hipLaunchKernelGGL((k_fuse_median3<RULE, 16, false>), dim3(grid), dim3(kBlock), 0, stream, a);
-  else if (rows == 4)
-    hipLaunchKernelGGL((k_fuse_median3<RULE, 4, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((k_fuse_median3<RULE, true>), dim3(grid), dim3(kFuseBlock), 0, stream, a);
   else
-    hipLaunchKernelGGL((k_fuse_median3<RULE, 8, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((k_fuse_median3<RULE, false>), dim3(grid), dim3(kFuseBlock), 0, stream, a);
 }
 }  // namespace
 
-// rows_hint: 0 = choose; 4, 8 or 16 = rows per wave (tuning).
+// rows_hint: 0 = choose; else rows per wave (tuning; even, 2..1024).
 hipError_t launch_fuse(FuseArgs a, hipStream_t stream, int rows_hint) {
-  // Taller strips re-read fewer halo rows but need more registers (fewer waves
-  // in flight); small launches want more, shorter strips.
+  // Tall strips amortise the one re-fused halo row; small launches want more, shorter strips so that
+  // every SIMD has waves to switch between.
   const uint32_t strips = (a.width + kStripCols - 1) / kStripCols;
-  uint32_t rows = (rows_hint == 4 || rows_hint == 8 || rows_hint == 16) ? uint32_t(rows_hint) : 0u;
-  if (!rows) rows = uint64_t(strips) * ((a.height + 15) / 16) * a.n_frames >= 8192u ? 16u : 8u;
-  if (a.width < 4) rows = 8;
+  uint32_t rows = (rows_hint >= 2 && rows_hint <= 1024) ? uint32_t(rows_hint) & ~1u : 0u;
+  if (!rows) {
+    // tools/fusion_bench.py: 16 rows (8 when the combined plane is written too) beat 4 and 32 on full
+    // launches; a single small frame wants more, shorter strips
+    rows = a.combined ? 8 : 16;
+    while (rows > 4 && uint64_t(strips) * ((a.height + rows - 1) / rows) * a.n_frames < 2048u) rows >>= 1;
+  }
+  a.rows_per_wave = rows;
   a.strips_x = strips;
   a.chunks_y = (a.height + rows - 1) / rows;
   const uint64_t items = uint64_t(a.strips_x) * a.chunks_y * a.n_frames;
   if (items == 0 || items > 0x7fffffffull) return hipErrorInvalidValue;
   a.items = uint32_t(items);
-  const uint32_t grid = (a.items + kBlock / 64 - 1) / (kBlock / 64);
+  const uint32_t grid = (a.items + kFuseBlock / 64 - 1) / (kFuseBlock / 64);
   switch (a.rule) {
-    case FUSE_WEIGHTED_AVERAGE: launch_rule<FUSE_WEIGHTED_AVERAGE>(a, rows, grid, stream); break;
-    case FUSE_MAX_DIST: launch_rule<FUSE_MAX_DIST>(a, rows, grid, stream); break;
-    case FUSE_MAX_DIST_UNLESS_BLACK: launch_rule<FUSE_MAX_DIST_UNLESS_BLACK>(a, rows, grid, stream); break;
-    case FUSE_BETTER_SCORE: launch_rule<FUSE_BETTER_SCORE>(a, rows, grid, stream); break;
-    case FUSE_ONLY_GOOD_1: launch_rule<FUSE_ONLY_GOOD_1>(a, rows, grid, stream); break;
-    case FUSE_ONLY_GOOD_AVG: launch_rule<FUSE_ONLY_GOOD_AVG>(a, rows, grid, stream); break;
-    case FUSE_OVERLAP: launch_rule<FUSE_OVERLAP>(a, rows, grid, stream); break;
-    case FUSE_BLACK_TO_WHITE: launch_rule<FUSE_BLACK_TO_WHITE>(a, rows, grid, stream); break;
-    case FUSE_GRAD_FILTER: launch_rule<FUSE_GRAD_FILTER>(a, rows, grid, stream); break;
+    case FUSE_WEIGHTED_AVERAGE: launch_rule<FUSE_WEIGHTED_AVERAGE>(a, grid, stream); break;
+    case FUSE_MAX_DIST: launch_rule<FUSE_MAX_DIST>(a, grid, stream); break;
+    case FUSE_MAX_DIST_UNLESS_BLACK: launch_rule<FUSE_MAX_DIST_UNLESS_BLACK>(a, grid, stream); break;
+    case FUSE_BETTER_SCORE: launch_rule<FUSE_BETTER_SCORE>(a, grid, stream); break;
+    case FUSE_ONLY_GOOD_1: launch_rule<FUSE_ONLY_GOOD_1>(a, grid, stream); break;
+    case FUSE_ONLY_GOOD_AVG: launch_rule<FUSE_ONLY_GOOD_AVG>(a, grid, stream); break;
+    case FUSE_OVERLAP: launch_rule<FUSE_OVERLAP>(a, grid, stream); break;
+    case FUSE_BLACK_TO_WHITE: launch_rule<FUSE_BLACK_TO_WHITE>(a, grid, stream); break;
+    case FUSE_GRAD_FILTER: launch_rule<FUSE_GRAD_FILTER>(a, grid, stream); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -58,7 +58,7 @@ struct FuseArgs {
   uint32_t width = 0, height = 0, n_frames = 1;
   int rule = FUSE_GRAD_FILTER;
   uint32_t crop_left = 0, crop_top = 0, out_width = 0, out_height = 0;
-  uint32_t strips_x = 0, chunks_y = 0, items = 0;  // filled by launch_fuse
+  uint32_t strips_x = 0, chunks_y = 0, items = 0, rows_per_wave = 0;  // filled by launch_fuse
 };
 hipError_t launch_fuse(FuseArgs a, hipStream_t stream, int rows_hint = 0);
 

@@ -296,7 +296,9 @@ int d2pc_crop_to_square(int cols, int rows, int offset_x, int offset_y, int memb
 
 /* Launch-shape tuning hook (no counterpart in the reference; results never
  * depend on it).  Keys: "pxt_parity", "pxt_compact" (ROI pixels per thread:
- * 4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by the tile count; 1..4096). */
+ * 4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by the tile count; 1..4096),
+ * "onepass_blocks_per_cu", "force_general_q", "no_vec_rows", "fuse_rows" (rows per wave of
+ * d2pc_fuse_device: 0 = choose, else even 2..1024). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

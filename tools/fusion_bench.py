@@ -46,9 +46,9 @@ for (n, f) in ((465, 1), (465, 64), (1080, 32), (2160, 16), (2160, 64)):
         px = f * n * n
         byts = px * ((6 + 1) if with_comb else 4) + f * ow * oh
         line = f"{n}x{n} x{f:3d} combined={int(with_comb)}:"
-        for rows in (0, 4, 8, 16):
+        for rows in (0, 4, 8, 16, 32):
             ctx.set_tuning("fuse_rows", rows)
             us = t(lambda: ctx.fuse_device(desc, s))
-            line += f"  rows={rows:2d} {us:7.1f} us {px/us/1e3:6.1f} Gpix/s {byts/us/1e3:6.0f} GB/s |"
+            line += f"  rows={rows:2d} {us:7.1f} us {px/us/1e3:6.1f} Gpix/s {byts/us/1e3:5.0f} GB/s |"
         print(line, flush=True)
 ctx.close()
