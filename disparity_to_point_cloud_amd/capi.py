@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "d2pc_check_async_error", "d2pc_set_tuning", "d2pc_median_device", "d2pc_process_mono8",
     "d2pc_pipeline_configure", "d2pc_pipeline_acquire", "d2pc_pipeline_submit", "d2pc_pipeline_collect",
     "d2pc_pipeline_release", "d2pc_fuse_desc_init", "d2pc_fuse_device", "d2pc_crop_to_square",
+    "d2pc_rotate_cw_device",
 ]
 # d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
 (FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
@@ -150,6 +151,8 @@ def load_library():
     L.d2pc_fuse_desc_init.argtypes = [ctypes.POINTER(FuseDesc)]
     L.d2pc_fuse_desc_init.restype = None
     L.d2pc_fuse_device.argtypes = [vp, ctypes.POINTER(FuseDesc), vp]
+    L.d2pc_rotate_cw_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                        vp, ctypes.c_size_t, ctypes.c_size_t, vp]
     L.d2pc_crop_to_square.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)] * 3
     L.d2pc_check_async_error.argtypes = [vp]
     L.d2pc_set_tuning.argtypes = [vp, cp, ctypes.c_int]
@@ -362,6 +365,12 @@ class Context:
     def fuse_device(self, desc: "FuseDesc", stream_ptr=None):
         """d2pc_fuse_device: fusion rule + combined confidence + 3x3 median + crop on device planes."""
         self._check(self._L.d2pc_fuse_device(self._h, ctypes.byref(desc), stream_ptr))
+
+    def rotate_cw_device(self, d_src_ptr, cols, rows, src_pitch, src_frame_stride, n_frames, d_dst_ptr, dst_pitch,
+                         dst_frame_stride, stream_ptr=None):
+        """d2pc_rotate_cw_device: dst(i, j) = src(rows-1-j, i) for 8-bit device frames."""
+        self._check(self._L.d2pc_rotate_cw_device(self._h, d_src_ptr, cols, rows, src_pitch, src_frame_stride, n_frames,
+                                                  d_dst_ptr, dst_pitch, dst_frame_stride, stream_ptr))
 
     # -- pipelined host path (d2pc_pipeline_*) ------------------------------
     def pipeline_configure(self, depth=3, direct_host_write=False):

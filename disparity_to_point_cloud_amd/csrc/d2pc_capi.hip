@@ -958,4 +958,36 @@ int d2pc_fuse_device(d2pc_ctx *ctx, const d2pc_fuse_desc *desc, void *stream) {
   return D2PC_OK;
 }
 
+int d2pc_rotate_cw_device(d2pc_ctx *ctx, const void *d_src, int cols, int rows, size_t src_pitch,
+                          size_t src_frame_stride, int n_frames, void *d_dst, size_t dst_pitch,
+                          size_t dst_frame_stride, void *stream) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!d_src || !d_dst) return fail(ctx, D2PC_ERR_INVALID_ARG, "null device pointer");
+  if (cols <= 0 || rows <= 0 || n_frames <= 0 || n_frames > 65535)
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "bad size %dx%d x%d", cols, rows, n_frames);
+  if (src_pitch < size_t(cols) || dst_pitch < size_t(rows) || src_pitch > 0xffffffffull || dst_pitch > 0xffffffffull)
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "pitch smaller than the row (src rows are %d, dst rows %d pixels)", cols, rows);
+  const size_t src_extent = size_t(rows - 1) * src_pitch + size_t(cols), dst_extent = size_t(cols - 1) * dst_pitch + size_t(rows);
+  if (n_frames > 1 && (src_frame_stride < src_extent || dst_frame_stride < dst_extent))
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "frame stride too small");
+  const uintptr_t s0 = reinterpret_cast<uintptr_t>(d_src), d0 = reinterpret_cast<uintptr_t>(d_dst);
+  const uintptr_t s1 = s0 + size_t(n_frames - 1) * src_frame_stride + src_extent;
+  const uintptr_t d1 = d0 + size_t(n_frames - 1) * dst_frame_stride + dst_extent;
+  if (s0 < d1 && d0 < s1) return fail(ctx, D2PC_ERR_INVALID_ARG, "source and destination overlap");
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  RotateArgs a;
+  a.src = static_cast<const uint8_t *>(d_src);
+  a.dst = static_cast<uint8_t *>(d_dst);
+  a.src_pitch = uint32_t(src_pitch);
+  a.dst_pitch = uint32_t(dst_pitch);
+  a.src_frame_stride = n_frames > 1 ? src_frame_stride : 0;
+  a.dst_frame_stride = n_frames > 1 ? dst_frame_stride : 0;
+  a.cols = uint32_t(cols);
+  a.rows = uint32_t(rows);
+  a.n_frames = uint32_t(n_frames);
+  D2PC_HIP(ctx, launch_rotate_cw(a, static_cast<hipStream_t>(stream)));
+  return D2PC_OK;
+}
+
 }  // extern "C"

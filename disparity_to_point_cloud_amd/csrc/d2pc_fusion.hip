@@ -351,4 +351,71 @@ hipError_t launch_fuse(FuseArgs a, hipStream_t stream, int rows_hint) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// rotateMat (reference src/depth_map_fusion.cpp:268-273): cv::transpose then
+// cv::flip(.., 1) = 90 degrees clockwise; dst has `cols` rows of `rows`
+// pixels, dst(i, j) = src(rows-1-j, i).  64 x 64 byte tiles through LDS: rows
+// are read and written as dwords, the transposition is the LDS gather.
+// ---------------------------------------------------------------------------
+constexpr int kRotTile = 64;
+
+__global__ __launch_bounds__(kBlock) void k_rotate_cw(const RotateArgs a) {
+  __shared__ uint8_t tile[kRotTile][kRotTile + 4];
+  uint32_t b = blockIdx.x;
+  const uint32_t f = b / (a.tiles_x * a.tiles_y);
+  b -= f * a.tiles_x * a.tiles_y;
+  const uint32_t ty = b / a.tiles_x, tx = b - ty * a.tiles_x;
+  const int c0 = int(tx) * kRotTile, r0 = int(ty) * kRotTile;  // source tile origin
+  const uint8_t *src = a.src + uint64_t(f) * a.src_frame_stride;
+  uint8_t *dst = a.dst + uint64_t(f) * a.dst_frame_stride;
+  const int cols = int(a.cols), rows = int(a.rows);
+  const int q = int(threadIdx.x & 15u) * 4, p = int(threadIdx.x >> 4);  // 16 dword columns x 16 rows per pass
+
+#pragma unroll
+  for (int k = 0; k < kRotTile / 16; ++k) {
+    const int r = p + 16 * k, y = r0 + r, x = c0 + q;
+    uint32_t v = 0;
+    if (y < rows) {
+      const uint8_t *row = src + uint64_t(y) * a.src_pitch;
+      if (x + 3 < cols) {
+        __builtin_memcpy(&v, row + x, 4);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (x + i < cols) v |= uint32_t(row[x + i]) << (8 * i);
+      }
+    }
+    __builtin_memcpy(&tile[r][q], &v, 4);
+  }
+  __syncthreads();
+  // destination tile: rows c0 .. c0+63 (source columns), columns rows-1-(r0+63) .. rows-1-r0
+  const int j0 = rows - 1 - (r0 + kRotTile - 1);
+#pragma unroll
+  for (int k = 0; k < kRotTile / 16; ++k) {
+    const int i = p + 16 * k;  // destination row inside the tile = source column
+    if (c0 + i >= cols) continue;
+    uint32_t v = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v |= uint32_t(tile[kRotTile - 1 - (q + t)][i]) << (8 * t);
+    uint8_t *row = dst + uint64_t(c0 + i) * a.dst_pitch;
+    const int j = j0 + q;  // destination column of byte 0 (negative for the rows past the image end)
+    if (j >= 0) {
+      __builtin_memcpy(row + j, &v, 4);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (j + t >= 0) row[j + t] = uint8_t(v >> (8 * t));
+    }
+  }
+}
+
+hipError_t launch_rotate_cw(RotateArgs a, hipStream_t stream) {
+  a.tiles_x = (a.cols + kRotTile - 1) / kRotTile;
+  a.tiles_y = (a.rows + kRotTile - 1) / kRotTile;
+  const uint64_t blocks = uint64_t(a.tiles_x) * a.tiles_y * a.n_frames;
+  if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_rotate_cw, dim3(uint32_t(blocks)), dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
+}
+
 }  // namespace d2pc

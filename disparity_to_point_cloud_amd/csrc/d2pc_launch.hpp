@@ -62,6 +62,17 @@ struct FuseArgs {
 };
 hipError_t launch_fuse(FuseArgs a, hipStream_t stream, int rows_hint = 0);
 
+// rotateMat (d2pc_fusion.hip): dst(i, j) = src(rows-1-j, i), dst is cols rows of `rows` pixels
+struct RotateArgs {
+  const uint8_t *src = nullptr;
+  uint8_t *dst = nullptr;
+  uint64_t src_frame_stride = 0, dst_frame_stride = 0;
+  uint32_t src_pitch = 0, dst_pitch = 0;
+  uint32_t cols = 0, rows = 0, n_frames = 1;
+  uint32_t tiles_x = 0, tiles_y = 0;  // filled by launch_rotate_cw
+};
+hipError_t launch_rotate_cw(RotateArgs a, hipStream_t stream);
+
 bool tile_shape_supported(int pxt);
 uint32_t frame_state_stride(uint32_t tiles_per_frame);
 size_t compact_state_bytes(const Geom &g);

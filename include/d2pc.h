@@ -288,6 +288,12 @@ void d2pc_fuse_desc_init(d2pc_fuse_desc *desc);
  * overlap the inputs or each other: the reference writes `combined` over
  * score1 in place (cpp:113), which a caller reproduces by swapping buffers. */
 int d2pc_fuse_device(d2pc_ctx *ctx, const d2pc_fuse_desc *desc, void *stream);
+/* rotateMat (src/depth_map_fusion.cpp:268-273: cv::transpose + cv::flip(.,1) = 90 degrees clockwise) of 8-bit
+ * frames on the device: dst has `cols` rows of `rows` pixels, dst(i,j) = src(rows-1-j, i).  What DisparityCb2 and
+ * MatchingScoreCb2 apply to camera 2's images before cropToSquare (cpp:56,84).  Asynchronous on `stream`. */
+int d2pc_rotate_cw_device(d2pc_ctx *ctx, const void *d_src, int cols, int rows, size_t src_pitch,
+                          size_t src_frame_stride, int n_frames, void *d_dst, size_t dst_pitch,
+                          size_t dst_frame_stride, void *stream);
 /* cropToSquare (src/depth_map_fusion.cpp:247-265): the square view of a
  * cols x rows image, shifted by the offsets.  The side length uses the class
  * member offset_y_ (cpp:253), the origin the argument: pass both. */

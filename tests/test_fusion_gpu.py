@@ -172,3 +172,69 @@ def test_rejects_bad_arguments():
         with pytest.raises(d2pc.D2pcError):
             ctx.fuse_device(d)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("rows,cols", [(480, 752), (752, 480), (64, 64), (65, 63), (1, 1), (1, 130), (130, 1), (3, 5),
+                                       (127, 129), (2160, 3840)])
+def test_rotate_cw_matches_oracle(rows, cols):
+    rng = np.random.default_rng(rows * 4099 + cols)
+    imgs = rng.integers(0, 256, size=(2, rows, cols)).astype(np.uint8)
+    src = torch.from_numpy(imgs).cuda()
+    dst = torch.full((2, cols, rows), 7, dtype=torch.uint8, device="cuda")
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        ctx.rotate_cw_device(src.data_ptr(), cols, rows, cols, cols * rows, 2, dst.data_ptr(), rows, rows * cols,
+                             torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        for f in range(2):
+            assert np.array_equal(got[f], oracle.rotate_cw(imgs[f]))
+        # pitched views in and out, single frame
+        big = torch.from_numpy(rng.integers(0, 256, size=(rows + 3, cols + 5)).astype(np.uint8)).cuda()
+        out = torch.zeros((cols + 2, rows + 9), dtype=torch.uint8, device="cuda")
+        view = big[2:2 + rows, 1:1 + cols]
+        ctx.rotate_cw_device(view.data_ptr(), cols, rows, big.stride(0), 0, 1, out[1:, 3:].data_ptr(), out.stride(0), 0)
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert np.array_equal(o[1:1 + cols, 3:3 + rows], oracle.rotate_cw(np.ascontiguousarray(view.cpu().numpy())))
+        assert not o[0].any() and not o[:, :3].any() and not o[:, 3 + rows:].any() and not o[1 + cols:].any()
+        for bad in ((0, rows), (cols, 0)):
+            with pytest.raises(d2pc.D2pcError):
+                ctx.rotate_cw_device(src.data_ptr(), bad[0], bad[1], cols, 0, 1, dst.data_ptr(), rows, 0)
+        with pytest.raises(d2pc.D2pcError):
+            ctx.rotate_cw_device(src.data_ptr(), cols, rows, cols - 1 if cols > 1 else 0, 0, 1, dst.data_ptr(), rows, 0)
+        with pytest.raises(d2pc.D2pcError):
+            ctx.rotate_cw_device(src.data_ptr(), cols, rows, cols, 0, 1, src.data_ptr(), rows, 0)
+
+
+def test_whole_fusion_front_end_on_device():
+    """Camera 2's planes rotated and both cameras' planes cropped to square on the device, as DisparityCb1/2 and
+    MatchingScoreCb1/2 do (src/depth_map_fusion.cpp:46-62, launch offsets -7/15), then fused."""
+    rng = np.random.default_rng(77)
+    H, W, ox, oy = 480, 752, -7, 15
+    raw = [rng.integers(0, 256, size=(H, W)).astype(np.uint8) for _ in range(4)]   # disp1, disp2, score1, score2
+    g = [rng.integers(0, 256, size=(465, 465)).astype(np.uint8) for _ in range(2)]  # the grads: host-filtered
+    # oracle chain
+    x1, y1, n = oracle.crop_to_square(W, H, ox, oy)
+    x2, y2, n2 = oracle.crop_to_square(H, W, -ox, -oy, oy)
+    assert n == n2 == 465
+    d1 = raw[0][y1:y1 + n, x1:x1 + n]
+    s1 = raw[2][y1:y1 + n, x1:x1 + n]
+    d2_ = oracle.rotate_cw(raw[1])[y2:y2 + n, x2:x2 + n]
+    s2 = oracle.rotate_cw(raw[3])[y2:y2 + n, x2:x2 + n]
+    want_f, want_c = oracle.fuse([np.ascontiguousarray(p) for p in (d1, d2_, s1, s2, g[0], g[1])])
+    # device chain
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        dev = [torch.from_numpy(r).cuda() for r in raw]
+        rot = [torch.empty((W, H), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        for src, dst in ((dev[1], rot[0]), (dev[3], rot[1])):
+            ctx.rotate_cw_device(src.data_ptr(), W, H, W, 0, 1, dst.data_ptr(), H, 0,
+                                 torch.cuda.current_stream().cuda_stream)
+        cx1, cy1, cn = d2pc.crop_to_square(W, H, ox, oy)
+        cx2, cy2, _ = d2pc.crop_to_square(H, W, -ox, -oy, oy)
+        planes = [dev[0][cy1:cy1 + cn, cx1:cx1 + cn], rot[0][cy2:cy2 + cn, cx2:cx2 + cn],
+                  dev[2][cy1:cy1 + cn, cx1:cx1 + cn], rot[1][cy2:cy2 + cn, cx2:cx2 + cn],
+                  torch.from_numpy(g[0]).cuda(), torch.from_numpy(g[1]).cuda()]
+        fused, comb = fuse_planes(ctx, planes)
+        torch.cuda.synchronize()
+    assert np.array_equal(fused.cpu().numpy(), want_f)
+    assert np.array_equal(comb.cpu().numpy(), want_c)
