@@ -261,6 +261,17 @@ void classify_q(d2pc_ctx *ctx) {
   ctx->qs.b = q[15] + z;
 }
 
+// The synchronous host entry points must not return (even with an error) while
+// work that reads the caller's input or writes the caller's output is in flight.
+struct SyncOnExit {
+  hipStream_t s;
+  bool armed = true;
+  explicit SyncOnExit(hipStream_t stream) : s(stream) {}
+  ~SyncOnExit() {
+    if (armed) (void)hipStreamSynchronize(s);
+  }
+};
+
 bool stream_is_capturing(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &st) != hipSuccess) return false;
@@ -617,6 +628,7 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
   if ((st = grow(ctx, &ctx->d_out, &ctx->out_cap, size_t(g.roi_n) * 16)) != D2PC_OK) return st;
   if (out_index && (st = grow(ctx, &ctx->d_idx, &ctx->idx_cap, size_t(g.roi_n) * 4)) != D2PC_OK) return st;
   hipStream_t s = ctx->stream;
+  SyncOnExit drain(s);
   D2PC_HIP(ctx, hipMemcpy2DAsync(ctx->d_in, pitch, disp, row_stride, size_t(width) * es, size_t(height),
                                  hipMemcpyHostToDevice, s));
   const void *kernel_in = ctx->d_in;
@@ -644,6 +656,7 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
     if (out_index) D2PC_HIP(ctx, hipMemcpyAsync(out_index, ctx->d_idx, n * 4, hipMemcpyDeviceToHost, s));
   }
   D2PC_HIP(ctx, hipStreamSynchronize(s));
+  drain.armed = false;
   *n_points = n;
   return D2PC_OK;
 }
@@ -777,6 +790,10 @@ int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
   int st = make_geom(ctx, d.dtype, d.scale, d.width, d.height, d.row_stride_bytes, 0, 1, 0,
                      compact ? ctx->pxt_compact : ctx->pxt_parity, &g);
   if (st != D2PC_OK) return st;
+  // the slot's buffers were sized at acquire time: a d2pc_set_border in between must not overflow them
+  if (g.roi_n != sl.roi_n)
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "border changed since slot %d was acquired (%zu -> %u ROI points): release it",
+                slot, sl.roi_n, g.roi_n);
   hipStream_t s = sl.stream;
   const size_t in_bytes = size_t(d.height) * d.row_stride_bytes;
   D2PC_HIP(ctx, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, s));
@@ -829,7 +846,11 @@ int d2pc_pipeline_collect(d2pc_ctx *ctx, int *slot, const void **points, const u
   if (ctx->cfg.mode == D2PC_MODE_COMPACT && ctx->last_compact_algo == 2 && sl.d_state) {
     StateHeader h;
     D2PC_HIP(ctx, hipMemcpy(&h, sl.d_state, sizeof h, hipMemcpyDeviceToHost));
-    if (h.timeout) return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
+    if (h.timeout) {
+      *slot = oldest;  // the frame is lost, but the slot can be released
+      sl.state = 3;
+      return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
+    }
   }
   *slot = oldest;
   *points = sl.h_out;

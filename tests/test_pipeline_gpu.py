@@ -90,3 +90,24 @@ def test_pipeline_misuse():
         ctx.pipeline_submit(np.ones((60, 60), np.float32), tag=9)
         p, _, tag, _ = ctx.pipeline_collect()
         assert p.shape == (0, 4) and tag == 9
+
+
+def test_border_change_between_acquire_and_submit_is_refused():
+    """The slot's buffers are sized when it is acquired; a smaller border afterwards would overflow them."""
+    import ctypes
+    from disparity_to_point_cloud_amd.capi import FrameDesc
+    q = d2pc.make_q()
+    fr = synth_disparity(6, 1, 320, 240, "uniform")
+    with d2pc.Context(q=q) as ctx:
+        ctx.pipeline_configure(depth=2)
+        desc = FrameDesc(d2pc.DTYPE_F32, 1.0, 320, 240, 320 * 4, 0, 0, 5)
+        host_in, slot = ctypes.c_void_p(), ctypes.c_int()
+        assert ctx._L.d2pc_pipeline_acquire(ctx._h, ctypes.byref(desc), ctypes.byref(host_in), ctypes.byref(slot)) == 0
+        ctx.set_border(0)                                   # ROI grows from 240x160 to 320x240 points
+        assert ctx._L.d2pc_pipeline_submit(ctx._h, slot.value) == 1
+        assert b"border changed" in ctx._L.d2pc_last_error(ctx._h)
+        assert ctx._L.d2pc_pipeline_release(ctx._h, slot.value) == 0
+        ctx.pipeline_submit(fr, tag=6)                      # a fresh acquire sizes for the new border
+        p, _, tag, _ = ctx.pipeline_collect()
+        assert tag == 6
+        assert_points_close(p, oracle.reproject(fr, q, border=0), max_ulp=1)
