@@ -33,12 +33,22 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //   loads : plain beats nt by 1-2 % (with a border the 256-B / 1-KiB wave
 //           pieces are not line-aligned; nt makes L2 drop the shared edge
 //           lines and re-fetch them: FETCH_SIZE 1.31x vs 1.07x algorithmic)
-//   stores: nt beats plain by ~2 % (points are written once, never re-read)
+//   stores: PARITY: nt beats plain by ~2 % (full aligned 1-KiB pieces, written once, never re-read);
+//           COMPACT single pass: plain -- survivors leave as ragged pieces whose end lines are
+//           completed by the neighbouring piece, so L2 should keep them to merge (30 % iid holes +
+//           indices: plain -5 % on one device, equal on another; never worse);
+//           COMPACT two-pass scatter: nt (-3..-7 % against plain, all cases)
 #ifndef D2PC_LOAD_NT
 #define D2PC_LOAD_NT 0
 #endif
 #ifndef D2PC_STORE_NT
 #define D2PC_STORE_NT 1
+#endif
+#ifndef D2PC_ONEPASS_STORE_NT
+#define D2PC_ONEPASS_STORE_NT 0
+#endif
+#ifndef D2PC_SCATTER_STORE_NT
+#define D2PC_SCATTER_STORE_NT 1
 #endif
 template <class T>
 __device__ __forceinline__ T ld(const T *p) {
@@ -48,13 +58,12 @@ __device__ __forceinline__ T ld(const T *p) {
   return *p;
 #endif
 }
-template <class T>
+template <bool NT, class T>
 __device__ __forceinline__ void st(T *p, T v) {
-#if D2PC_STORE_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
+  if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
 }
 
 // --------------------------------------------------------------------------
@@ -130,11 +139,12 @@ __device__ __forceinline__ bool point_is_valid(float X, float Y, float Z, float 
   return (int(fabsf(X) < inf) & int(fabsf(Y) < inf) & int(fabsf(Z) < inf) & int(!(d <= min_disparity))) != 0;
 }
 
+template <bool NT>
 __device__ __forceinline__ void store_point(float4 *frame_out, uint32_t point, float X, float Y, float Z) {
   // pcl::PointXYZ = {x,y,z,1.0f} (cpp:74): one global_store_dwordx4 with an
   // SGPR base and a 32-bit byte offset (host guarantees roi_n <= 2^28).
   const v4f p = {X, Y, Z, 1.0f};
-  st(reinterpret_cast<v4f *>(reinterpret_cast<uint8_t *>(frame_out) + (point << 4)), p);
+  st<NT>(reinterpret_cast<v4f *>(reinterpret_cast<uint8_t *>(frame_out) + (point << 4)), p);
 }
 
 __device__ __forceinline__ void store_index(uint32_t *frame_idx, uint32_t point, uint32_t pix) {
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void k_reproject_pack(const uint8_t *__rest
     for (int k = 0; k < PXT; ++k) {
       const uint32_t i = slot_pixel(base, wave, lane, k);
       if (i < g.roi_n) {
-        store_point(fout, i, r.X[k], r.Y[k], r.Z[k]);
+        store_point<D2PC_STORE_NT != 0>(fout, i, r.X[k], r.Y[k], r.Z[k]);
         if (fidx) store_index(fidx, i, r.pix[k]);
       }
     }
@@ -486,7 +496,7 @@ __device__ __forceinline__ void tile_scatter(const TileRegs<DT, QK, PXT> &r, con
     // pos < roi_n always holds for a correct prefix; the guard keeps a stale
     // or timed-out prefix from ever becoming an out-of-bounds store
     if (((mask[k] >> lane) & 1) && pos < roi_n) {
-      store_point(fout, pos, r.X[k], r.Y[k], r.Z[k]);
+      store_point<D2PC_SCATTER_STORE_NT != 0>(fout, pos, r.X[k], r.Y[k], r.Z[k]);
       if (fidx) store_index(fidx, pos, r.pix[k]);
     }
   }
@@ -788,7 +798,7 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
             reproject(Q, uu[k], vv[k], dq[k], X, Y, Z);
             const uint32_t pos = prefix + qexcl[k] + mbcnt64(qmask[k]);
             if (((qmask[k] >> lane) & 1) && pos < g.roi_n) {
-              store_point(fout, pos, X, Y, Z);
+              store_point<D2PC_ONEPASS_STORE_NT != 0>(fout, pos, X, Y, Z);
               if (fidx) store_index(fidx, pos, vv[k] * g.width + uu[k]);
             }
           }
