@@ -109,20 +109,34 @@ def test_batched_views_with_pitches_and_aliasing():
         assert np.array_equal(comb[f].cpu().numpy(), want_c)
 
 
-def test_large_batch_takes_the_tall_strip_kernel():
+@pytest.mark.parametrize("rows", [0, 2, 4, 6, 16, 30, 32, 1024])
+def test_any_strip_height_gives_the_same_image(rows):
+    """The rolling window walks `fuse_rows` rows per wave (two per step, alternating register sets):
+    odd heights, heights below one strip and strips of 4k+2 rows all have to land on the same bytes."""
     rng = np.random.default_rng(11)
-    F, H, W = 4, 2160, 2160  # 9 strips x 135 chunks x 4 = 4860 < 8192 -> 8-row kernel
-    planes8 = [rng.integers(0, 256, size=(1, 300, 500)).astype(np.uint8) for _ in range(6)]
-    planes16 = [np.broadcast_to(rng.integers(0, 256, size=(1, H, W)).astype(np.uint8), (F, H, W)).copy()
-                for _ in range(6)]
-    planes16 = [np.concatenate([p, p], axis=0) for p in planes16]  # 8 frames -> 9720 items -> 16-row kernel
     with d2pc.Context(q=d2pc.make_q()) as ctx:
-        for planes in (planes8, planes16):
-            fused, comb = _gpu(ctx, planes)
-            want_f, want_c = oracle.fuse([p[0] for p in planes])
-            for f in range(planes[0].shape[0]):
-                assert np.array_equal(fused[f], want_f)
-                assert np.array_equal(comb[f], want_c)
+        ctx.set_tuning("fuse_rows", rows)
+        for h, w in ((301, 500), (31, 249), (2, 9), (33, 4)):
+            planes = _planes(rng, h, w, "thresholds")
+            fused, comb = _gpu(ctx, planes, crop=(1, 2, 0, 1))
+            want_f, want_c = oracle.fuse(planes, crop=(1, 2, 0, 1))
+            assert np.array_equal(fused, want_f), (rows, h, w)
+            assert np.array_equal(comb, want_c), (rows, h, w)
+        with pytest.raises(d2pc.D2pcError):
+            ctx.set_tuning("fuse_rows", 1)
+
+
+def test_full_size_batch():
+    rng = np.random.default_rng(12)
+    one = [rng.integers(0, 256, size=(1, 2160, 2160)).astype(np.uint8) for _ in range(6)]
+    planes = [np.concatenate([p, p[:, ::-1].copy(), p], axis=0) for p in one]   # 3 frames, the middle one flipped
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        fused, comb = _gpu(ctx, planes)
+    for f in (0, 1):
+        want_f, want_c = oracle.fuse([np.ascontiguousarray(p[f]) for p in planes])
+        assert np.array_equal(fused[f], want_f)
+        assert np.array_equal(comb[f], want_c)
+    assert np.array_equal(fused[2], fused[0]) and np.array_equal(comb[2], comb[0])
 
 
 def test_without_combined_grads_may_be_null():
