@@ -2,18 +2,24 @@
 // BORDER_REPLICATE: the device form of cv::medianBlur(img, out, 11) at
 // reference src/disparity_to_point_cloud.cpp:55-57.
 //
-// Bit-plane radix select (no sorting, no histograms):
-//  1. A block owns 16 x 64 output pixels.  Every input row of the tile (+halo)
-//     is turned into eight 32-bit PLANE WORDS, bit j of plane b = bit b of the
-//     pixel in column c0-r+j, by one lane per row with in-register bit
-//     transposes.  The words go to LDS: plane[b][row].
-//  2. The median of the k*k window of pixel (y,x) is found MSB-first.  The
-//     candidate set is k row masks (k consecutive bits starting at bit x);
-//     per plane: ones = cand & plane word, n1 = popcount (v_bcnt accumulates),
-//     the rank decides whether the median's bit is 0 or 1 and the candidates
-//     shrink to the matching half.  8 planes x k rows x 3 integer ops (and,
-//     bcnt-accumulate, bitop3): ~280 ops per pixel for k = 11, against 2 x 968
-//     for compare-and-count.
+// Bit-plane radix select (no sorting, no histograms), two window rows per
+// register:
+//  1.  A block owns TW x 64 output pixels.  Every input row of the tile (+halo)
+//      is turned into eight 32-bit PLANE WORDS, bit j of plane b = bit b of the
+//      pixel in column c0-r+j, by one lane per row with in-register bit
+//      transposes (four 8x8 bit transposes and two 4x4 byte transposes: ~110
+//      integer ops for all eight words of a row).  The words are cut into
+//      overlapping 16-bit SEGMENTS (one every 17-k columns, so that every pixel
+//      finds its whole k-bit window inside one segment) and the segments of
+//      rows i and i+1 (the neighbouring lane's: one DPP move) are packed into
+//      one dword in LDS: pair[b][segment][i] = seg(i) | seg(i+1) << 16.
+//  2.  The median of the k*k window of pixel (y,x) is found MSB-first.  The
+//      candidate set is ceil(k/2) registers, each holding the k-bit masks of TWO
+//      window rows; per plane and register: ones = cand & pair word, n1 +=
+//      popcount, and after the rank test cand &= pair ^ flip -- three integer
+//      instructions (v_and, v_bcnt accumulate, v_bitop3) for two rows.
+//      k = 11: 8 planes x 6 registers x 3 = 144 ops per pixel (one row per
+//      register: 264; compare-and-count: 2 x 968).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -21,33 +27,52 @@
 
 namespace d2pc {
 
-constexpr int kMedTileW = 16, kMedTileH = 64;
+namespace {
 
 template <int KS>
-__global__ __launch_bounds__(kBlock) void k_median_u8(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                      const MedianArgs a) {
-  constexpr int R = KS / 2;
-  constexpr int IN_ROWS = kMedTileH + 2 * R;
-  constexpr int PAIRS = (IN_ROWS + 1) / 2;
-  __shared__ uint32_t s_plane[8][2 * PAIRS];
+struct MedianShape {
+  static constexpr int R = KS / 2;
+  static constexpr int SEG_PX = 17 - KS;           // output pixels served by one 16-bit segment
+  static constexpr int NSEG = 16 / SEG_PX + 1;     // segments cut from a 32-bit plane word
+  static constexpr int TW = NSEG * SEG_PX;         // tile width  (k=11: 18, 9: 24, 7: 20, 5: 24, 3: 28)
+  static constexpr int TH = 64;                    // tile height
+  static constexpr int IN_ROWS = TH + 2 * R;
+  static constexpr int NREG = (KS + 1) / 2;        // row pairs per window
+  static constexpr int THREADS = (TW * TH) % 256 == 0 ? 256 : 192;
+  static_assert((NSEG - 1) * SEG_PX + 16 <= 32, "segments must lie inside the plane word");
+  static_assert(TW + KS - 1 <= 32, "the tile's windows must lie inside the plane word");
+  static_assert((TW * TH) % THREADS == 0, "whole passes over the tile");
+  static_assert(IN_ROWS <= 2 * 63 && THREADS >= 128, "two waves of 63 row pairs cover the input rows");
+};
+
+}  // namespace
+
+template <int KS>
+__global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const uint8_t *__restrict__ src,
+                                                                        uint8_t *__restrict__ dst,
+                                                                        const MedianArgs a) {
+  using S = MedianShape<KS>;
+  constexpr int R = S::R, IN_ROWS = S::IN_ROWS;
+  __shared__ uint32_t s_pair[8][S::NSEG][IN_ROWS];
   const uint32_t tid = threadIdx.x;
 
   uint32_t b = blockIdx.x;
   const uint32_t f = b / (a.tiles_x * a.tiles_y);
   b -= f * a.tiles_x * a.tiles_y;
   const uint32_t ty = b / a.tiles_x, tx = b - ty * a.tiles_x;
-  const int c0 = int(tx) * kMedTileW, y0 = int(ty) * kMedTileH;
+  const int c0 = int(tx) * S::TW, y0 = int(ty) * S::TH;
   const uint8_t *fsrc = src + uint64_t(f) * a.src_frame_stride;
   uint8_t *fdst = dst + uint64_t(f) * a.dst_frame_stride;
 
-  // ---- 1. bit planes of the tile's input rows: one LANE per row -----------------
-  // Thread t < IN_ROWS fetches the 32 pixels of input row t and bit-transposes them in registers
-  // (four 8x8 bit transposes + a 4x4 byte transpose per half: ~110 integer ops for all eight plane
-  // words of the row).  One ballot per plane and row pair did the same with ~20 instructions per
-  // row pair in EVERY wave: 1600 wave instructions per block against ~300 now.
-  if (tid < uint32_t(IN_ROWS)) {
-    int iy = y0 - R + int(tid);
-    iy = iy < 0 ? 0 : iy >= int(a.height) ? int(a.height) - 1 : iy;  // replicate
+  // ---- 1. packed plane segments of the tile's input rows: one LANE per row ---------
+  // Wave w takes input rows 63w .. 63w+63: lane l needs the plane words of the row below it, which
+  // lane l+1 of the SAME wave holds (one DPP move per plane); lane 63 only serves as that partner,
+  // its own row is lane 0 of the next wave.  Two waves cover the <= 74 rows.
+  const uint32_t lane = tid & 63u;
+  const uint32_t in_row = (tid >> 6) * 63u + lane;
+  if ((tid >> 6) * 63u < uint32_t(IN_ROWS)) {  // wave-uniform
+    int iy = y0 - R + int(in_row);
+    iy = iy < 0 ? 0 : iy >= int(a.height) ? int(a.height) - 1 : iy;  // replicate (also keeps rows past IN_ROWS in bounds)
     const uint8_t *row = fsrc + uint64_t(iy) * a.src_row_stride;
     const int cl = c0 - R;  // column of bit 0
     uint32_t px[8];         // pixels cl .. cl+31, four per dword
@@ -79,79 +104,100 @@ __global__ __launch_bounds__(kBlock) void k_median_u8(const uint8_t *__restrict_
       px[j] = lo, px[j + 1] = hi;
     }
     // plane p = byte p of the four blocks: a 4x4 byte transpose of the lows (planes 0..3) and of the highs
+    uint32_t plane[8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t b0 = px[h], b1 = px[2 + h], b2 = px[4 + h], b3 = px[6 + h];
       const uint32_t a0 = __builtin_amdgcn_perm(b1, b0, 0x05010400u), a1 = __builtin_amdgcn_perm(b1, b0, 0x07030602u);
       const uint32_t a2 = __builtin_amdgcn_perm(b3, b2, 0x05010400u), a3 = __builtin_amdgcn_perm(b3, b2, 0x07030602u);
-      s_plane[4 * h + 0][tid] = __builtin_amdgcn_perm(a2, a0, 0x05040100u);
-      s_plane[4 * h + 1][tid] = __builtin_amdgcn_perm(a2, a0, 0x07060302u);
-      s_plane[4 * h + 2][tid] = __builtin_amdgcn_perm(a3, a1, 0x05040100u);
-      s_plane[4 * h + 3][tid] = __builtin_amdgcn_perm(a3, a1, 0x07060302u);
+      plane[4 * h + 0] = __builtin_amdgcn_perm(a2, a0, 0x05040100u);
+      plane[4 * h + 1] = __builtin_amdgcn_perm(a2, a0, 0x07060302u);
+      plane[4 * h + 2] = __builtin_amdgcn_perm(a3, a1, 0x05040100u);
+      plane[4 * h + 3] = __builtin_amdgcn_perm(a3, a1, 0x07060302u);
+    }
+    // 16-bit segments of this row and the next, packed
+    const bool writer = lane < 63u && in_row < uint32_t(IN_ROWS);
+#pragma unroll
+    for (int pl = 0; pl < 8; ++pl) {
+      const uint32_t below = uint32_t(__builtin_amdgcn_update_dpp(0, int(plane[pl]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+#pragma unroll
+      for (int sg = 0; sg < S::NSEG; ++sg) {
+        const uint32_t v = ((plane[pl] >> (sg * S::SEG_PX)) & 0xffffu) | ((below >> (sg * S::SEG_PX)) << 16);
+        if (writer) s_pair[pl][sg][in_row] = v;
+      }
     }
   }
   __syncthreads();
 
-  // ---- 2. radix select per output pixel ---------------------------------------
+  // ---- 2. radix select per output pixel ---------------------------------------------
   constexpr uint32_t kField = (1u << KS) - 1u;
 #pragma unroll 1
-  for (int i = 0; i < kMedTileW * kMedTileH / kBlock; ++i) {
-    const uint32_t p = tid + uint32_t(i) * kBlock;
-    const uint32_t y = p >> 4, x = p & 15u;
-    uint32_t cand[KS];
+  for (int it = 0; it < S::TW * S::TH / S::THREADS; ++it) {
+    const uint32_t p = tid + uint32_t(it) * uint32_t(S::THREADS);
+    const uint32_t y = p / uint32_t(S::TW), x = p - y * uint32_t(S::TW);
+    const uint32_t sg = x / uint32_t(S::SEG_PX), xs = x - sg * uint32_t(S::SEG_PX);
+    const uint32_t one_row = kField << xs;  // <= 16 bits by construction
+    uint32_t cand[S::NREG];
 #pragma unroll
-    for (int r = 0; r < KS; ++r) cand[r] = kField << x;
+    for (int j = 0; j < S::NREG; ++j) cand[j] = one_row | (one_row << 16);
+    if (KS & 1) cand[S::NREG - 1] = one_row;  // the last register holds one window row only
     uint32_t rank = uint32_t(KS * KS / 2) + 1u;  // 1-based rank of the median
     uint32_t ncand = uint32_t(KS * KS);
-    uint32_t med = 0;
+    uint32_t flips = 0;  // one bit per plane: 1 where the median's bit is 0
 #pragma unroll
     for (int pl = 7; pl >= 0; --pl) {
-      uint32_t word[KS];
+      uint32_t word[S::NREG];
       uint32_t n1 = 0;
 #pragma unroll
-      for (int r = 0; r < KS; ++r) {
-        word[r] = s_plane[pl][y + uint32_t(r)];
-        n1 += uint32_t(__popc(cand[r] & word[r]));
+      for (int j = 0; j < S::NREG; ++j) {
+        word[j] = s_pair[pl][sg][y + 2u * uint32_t(j)];
+        n1 += uint32_t(__popc(cand[j] & word[j]));
       }
       const uint32_t n0 = ncand - n1;
       const bool bit1 = rank > n0;  // the median is among the elements whose bit is 1
-      // keep the candidates whose bit equals the median's: cand & (word ^ flip) is ONE v_bitop3 per row
-      // (as an intrinsic: written with operators, LLVM folds it into the next plane's AND and spends
-      // a fourth instruction per row on the shared word ^ flip)
+      // keep the candidates whose bit equals the median's: cand & (word ^ flip) is ONE v_bitop3 per
+      // register (as an intrinsic: written with operators, LLVM folds it into the next plane's AND
+      // and spends a fourth instruction on the shared word ^ flip)
       const uint32_t flip = bit1 ? 0u : ~0u;
       if (pl > 0) {
 #pragma unroll
-        for (int r = 0; r < KS; ++r) cand[r] = __builtin_amdgcn_bitop3_b32(word[r], cand[r], flip, 0x48);
+        for (int j = 0; j < S::NREG; ++j) cand[j] = __builtin_amdgcn_bitop3_b32(word[j], cand[j], flip, 0x48);
       }
       rank = bit1 ? rank - n0 : rank;
       ncand = bit1 ? n1 : n0;
-      med |= bit1 ? (1u << pl) : 0u;
+      flips = (flips << 1) | (flip & 1u);
     }
     const uint32_t oy = uint32_t(y0) + y, ox = uint32_t(c0) + x;
-    if (oy < a.height && ox < a.width) fdst[uint64_t(oy) * a.dst_row_stride + ox] = uint8_t(med);
+    if (oy < a.height && ox < a.width) fdst[uint64_t(oy) * a.dst_row_stride + ox] = uint8_t(~flips);
   }
 }
 
 bool median_ksize_supported(int k) { return k == 3 || k == 5 || k == 7 || k == 9 || k == 11; }
 
-hipError_t launch_median(const void *src, void *dst, const MedianArgs &a0, int ksize, hipStream_t stream) {
-  MedianArgs a = a0;
-  a.tiles_x = (a.width + kMedTileW - 1) / kMedTileW;
-  a.tiles_y = (a.height + kMedTileH - 1) / kMedTileH;
+namespace {
+template <int KS>
+hipError_t launch_k(const uint8_t *s, uint8_t *d, MedianArgs a, hipStream_t stream) {
+  using S = MedianShape<KS>;
+  a.tiles_x = (a.width + S::TW - 1) / S::TW;
+  a.tiles_y = (a.height + S::TH - 1) / S::TH;
   const uint64_t blocks = uint64_t(a.tiles_x) * a.tiles_y * a.n_frames;
   if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
-  const dim3 grid{uint32_t(blocks)}, block{kBlock};
+  hipLaunchKernelGGL(k_median_u8<KS>, dim3(uint32_t(blocks)), dim3(S::THREADS), 0, stream, s, d, a);
+  return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_median(const void *src, void *dst, const MedianArgs &a, int ksize, hipStream_t stream) {
   const uint8_t *s = static_cast<const uint8_t *>(src);
   uint8_t *d = static_cast<uint8_t *>(dst);
   switch (ksize) {
-    case 3: hipLaunchKernelGGL(k_median_u8<3>, grid, block, 0, stream, s, d, a); break;
-    case 5: hipLaunchKernelGGL(k_median_u8<5>, grid, block, 0, stream, s, d, a); break;
-    case 7: hipLaunchKernelGGL(k_median_u8<7>, grid, block, 0, stream, s, d, a); break;
-    case 9: hipLaunchKernelGGL(k_median_u8<9>, grid, block, 0, stream, s, d, a); break;
-    case 11: hipLaunchKernelGGL(k_median_u8<11>, grid, block, 0, stream, s, d, a); break;
+    case 3: return launch_k<3>(s, d, a, stream);
+    case 5: return launch_k<5>(s, d, a, stream);
+    case 7: return launch_k<7>(s, d, a, stream);
+    case 9: return launch_k<9>(s, d, a, stream);
+    case 11: return launch_k<11>(s, d, a, stream);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 }  // namespace d2pc
