@@ -141,9 +141,11 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const ui
 #pragma unroll
     for (int j = 0; j < S::NREG; ++j) cand[j] = one_row | (one_row << 16);
     if (KS & 1) cand[S::NREG - 1] = one_row;  // the last register holds one window row only
-    uint32_t rank = uint32_t(KS * KS / 2) + 1u;  // 1-based rank of the median
-    uint32_t ncand = uint32_t(KS * KS);
-    uint32_t flips = 0;  // one bit per plane: 1 where the median's bit is 0
+    // With c candidates left and the median the (a+1)-th smallest of them, only d = c - a - 1 has to
+    // be carried: the median's bit is 1  <=>  zeros <= a  <=>  z = d - ones < 0; then d stays (c and a
+    // shrink by the same number of zeros), otherwise d = z.  Five integer ops per plane.
+    int32_t d = KS * KS - (KS * KS / 2 + 1);
+    int32_t acc = 0;  // minus the median, built MSB first
 #pragma unroll
     for (int pl = 7; pl >= 0; --pl) {
       uint32_t word[S::NREG];
@@ -153,22 +155,20 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const ui
         word[j] = s_pair[pl][sg][y + 2u * uint32_t(j)];
         n1 += uint32_t(__popc(cand[j] & word[j]));
       }
-      const uint32_t n0 = ncand - n1;
-      const bool bit1 = rank > n0;  // the median is among the elements whose bit is 1
-      // keep the candidates whose bit equals the median's: cand & (word ^ flip) is ONE v_bitop3 per
+      const int32_t z = d - int32_t(n1);
+      const int32_t is1 = z >> 31;  // all ones when the median's bit is 1
+      // keep the candidates whose bit equals the median's: cand & ~(word ^ is1) is ONE v_bitop3 per
       // register (as an intrinsic: written with operators, LLVM folds it into the next plane's AND
-      // and spends a fourth instruction on the shared word ^ flip)
-      const uint32_t flip = bit1 ? 0u : ~0u;
+      // and spends a fourth instruction on the shared term)
       if (pl > 0) {
 #pragma unroll
-        for (int j = 0; j < S::NREG; ++j) cand[j] = __builtin_amdgcn_bitop3_b32(word[j], cand[j], flip, 0x48);
+        for (int j = 0; j < S::NREG; ++j) cand[j] = __builtin_amdgcn_bitop3_b32(word[j], cand[j], uint32_t(is1), 0x84);
       }
-      rank = bit1 ? rank - n0 : rank;
-      ncand = bit1 ? n1 : n0;
-      flips = (flips << 1) | (flip & 1u);
+      d = z + (int32_t(n1) & is1);
+      acc = (acc << 1) + is1;
     }
     const uint32_t oy = uint32_t(y0) + y, ox = uint32_t(c0) + x;
-    if (oy < a.height && ox < a.width) fdst[uint64_t(oy) * a.dst_row_stride + ox] = uint8_t(~flips);
+    if (oy < a.height && ox < a.width) fdst[uint64_t(oy) * a.dst_row_stride + ox] = uint8_t(-acc);
   }
 }
 
