@@ -252,3 +252,22 @@ def test_whole_fusion_front_end_on_device():
         torch.cuda.synchronize()
     assert np.array_equal(fused.cpu().numpy(), want_f)
     assert np.array_equal(comb.cpu().numpy(), want_c)
+
+
+def test_gpu_matches_the_exact_rational_golden_vectors(golden_dir):
+    """tests/golden/fusion_rules.npz (make_fusion_golden.py: gradFilter in exact rationals, numpy median)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "fusion_rules.npz"))
+    planes = [np.ascontiguousarray(g[f"image__plane{k}"]) for k in range(6)]
+    d = np.arange(256, dtype=np.uint8)
+    d1, d2 = np.meshgrid(d, d, indexing="ij")
+    d1 = np.repeat(np.repeat(d1, 3, axis=0), 3, axis=1)  # constant 3x3 cells: the median is the identity at the centres
+    d2 = np.repeat(np.repeat(d2, 3, axis=0), 3, axis=1)
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        fused, comb = _gpu(ctx, planes)
+        assert np.array_equal(fused, g["image__fused"])
+        assert np.array_equal(comb, g["image__combined"])
+        for s1, s2 in g["score_pairs"]:
+            tab, _ = _gpu(ctx, [d1, d2, np.full_like(d1, s1), np.full_like(d1, s2), d1, d2], crop=(0, 0, 0, 0),
+                          want_combined=False)
+            assert np.array_equal(tab[1::3, 1::3], g[f"grad_filter__{s1}_{s2}"]), (s1, s2)

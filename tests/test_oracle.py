@@ -287,3 +287,18 @@ def test_crop_to_square_and_rotate():
     assert np.array_equal(oracle.rotate_cw(a), np.array([[3, 0], [4, 1], [5, 2]], dtype=np.uint8))
     img = np.random.default_rng(1).integers(0, 256, size=(37, 91)).astype(np.uint8)
     assert np.array_equal(oracle.rotate_cw(img), np.rot90(img, -1))
+
+
+def test_fusion_oracle_vs_exact_golden(golden_dir):
+    """tests/golden/fusion_rules.npz: gradFilter evaluated with exact rationals (make_fusion_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "fusion_rules.npz"))
+    assert bool(g["ratio_ok"][80, 100]) and not bool(g["ratio_ok"][100, 80])
+    for s1, s2 in g["score_pairs"]:
+        want = g[f"grad_filter__{s1}_{s2}"]
+        got = np.array([[oracle.fuse_pixel(oracle.FUSE_GRAD_FILTER, a, b, int(s1), int(s2)) for b in range(256)]
+                        for a in range(256)], dtype=np.uint8)
+        assert np.array_equal(got, want), (s1, s2)
+    planes = [np.ascontiguousarray(g[f"image__plane{k}"]) for k in range(6)]
+    fused, comb = oracle.fuse(planes)
+    assert np.array_equal(fused, g["image__fused"])
+    assert np.array_equal(comb, g["image__combined"])
