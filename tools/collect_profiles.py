@@ -97,7 +97,7 @@ if main:
         traffic["compact_border40_frames16"] = {
             "hbm_bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb,
             "source": f"profiles/{rnd}_pmc_summary.json (all compaction kernels of one step: the single-pass kernel "
-                      f"for batches >= 8 frames, else count + scan + scatter)"}
+                      f"for launches of >= 4 frames and >= 24576 tiles, else count + scan + scatter)"}
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
 print(json.dumps(traffic, indent=1))
