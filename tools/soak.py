@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Randomised soak of the device-resident entry point against the oracle: random frame counts,
+sizes, borders, dtypes, hole patterns, both compaction algorithms, index on/off, general and
+stereoRectify-structured Q.  Not part of the test suites (minutes); run on the GPU box:
+    python tools/soak.py [cases] [seed]
+"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import disparity_to_point_cloud_amd as d2pc
+from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+import oracle
+from helpers import assert_points_close
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+t0 = time.time()
+for c in range(cases):
+    n = int(rng.choice([1, 2, 3, 4, 5, 8, 13, 20]))
+    w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+    if rng.random() < 0.15:
+        w, h = int(rng.choice([752, 1920, 640])), int(rng.choice([480, 1080]))
+        n = min(n, 5)
+    border = int(rng.choice([0, 0, 1, 3, 8, 40, 40, 57]))
+    dt = rng.choice(["f32", "u8", "u16"])
+    mode = rng.choice(["parity", "compact"])
+    algo = int(rng.choice([0, 1, 2]))
+    idx = bool(rng.random() < 0.5)
+    holes = float(rng.choice([0.0, 0.05, 0.3, 0.9, 1.0]))
+    stereo = bool(rng.random() < 0.7)
+    q = d2pc.make_q()
+    if not stereo:
+        q = rng.uniform(-2, 2, 16)
+        q[12:14] = rng.uniform(0, 1e-3, 2); q[14] = rng.uniform(0.01, 1); q[15] = rng.uniform(0.1, 2)
+    elif rng.random() < 0.3:
+        q = d2pc.make_q(fx=500 + 300 * rng.random(), fy=600 + 200 * rng.random(), cx=w / 2, cy=h / 2, baseline=0.05 + rng.random(), nx=w + 1, ny=h + 1)
+    if dt == "f32":
+        frames = rng.uniform(0.5, 128, size=(n, h, w)).astype(np.float32); scale = 1.0; tdt = torch.float32
+    elif dt == "u8":
+        frames = rng.integers(1, 256, size=(n, h, w)).astype(np.uint8); scale = 0.125; tdt = torch.uint8
+    else:
+        frames = rng.integers(1, 65536, size=(n, h, w)).astype(np.uint16); scale = 1.0 / 64; tdt = torch.uint16
+    frames[rng.random((n, h, w)) < holes] = 0
+    m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
+    with d2pc.Context(q=q, border=border, mode=m, compact_algo=algo) as ctx:
+        b = DeviceBatch(ctx, n, h, w, dtype=tdt, want_index=idx)
+        b.disp.copy_(torch.from_numpy(frames.view(np.int16) if dt == "u16" else frames).view(tdt))
+        b.launch(scale=scale)
+        res = b.results()
+        if m == d2pc.MODE_COMPACT:
+            ctx.check_async_error()
+    # A dense Q can make a numerator cancel to ~1e-9 of its terms somewhere in a few million pixels; OpenCV 2.4's
+    # per-pixel increments (the oracle's form) and the kernel's fused multiply-adds then differ by a few float ulps
+    # there -- both are legitimate double evaluations.  stereoRectify-structured Q has no such sums: 1 ulp.
+    ulp = 1 if stereo else 64
+    what = f"case {c}: n={n} {w}x{h} b={border} {dt} {mode} algo={algo} idx={idx} holes={holes} stereo={stereo}"
+    for f in range(n):
+        if m == d2pc.MODE_PARITY:
+            want = oracle.reproject(frames[f], q, border=border, scale=scale)
+            assert_points_close(res[f][0], want, max_ulp=ulp, rel=1e-5, what=what)
+            if idx:
+                rw, rh = max(w - 2 * border, 0), max(h - 2 * border, 0)
+                vv, uu = np.divmod(np.arange(rw * rh), max(rw, 1))
+                assert np.array_equal(res[f][1], ((vv + border) * w + uu + border).astype(np.uint32)), what
+        else:
+            wp, wi = oracle.reproject_compact(frames[f], q, border=border, scale=scale)
+            assert len(res[f][0]) == len(wp), what + f" frame {f}: {len(res[f][0])} vs {len(wp)} points"
+            assert_points_close(res[f][0], wp, max_ulp=ulp, rel=1e-5, what=what)
+            if idx:
+                assert np.array_equal(res[f][1], wi), what
+    if c % 20 == 19:
+        print(f"{c + 1} cases ok ({time.time() - t0:.0f} s)", flush=True)
+print("soak ok:", cases, "cases")
