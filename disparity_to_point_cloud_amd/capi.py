@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "d2pc_check_async_error", "d2pc_set_tuning", "d2pc_median_device", "d2pc_process_mono8",
     "d2pc_pipeline_configure", "d2pc_pipeline_acquire", "d2pc_pipeline_submit", "d2pc_pipeline_collect",
     "d2pc_pipeline_release", "d2pc_fuse_desc_init", "d2pc_fuse_device", "d2pc_crop_to_square",
-    "d2pc_rotate_cw_device",
+    "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16",
 ]
 # d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
 (FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
@@ -141,6 +141,10 @@ def load_library():
                                      vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp]
     L.d2pc_process_mono8.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_float,
                                      vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.d2pc_process_mono16.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_float,
+                                      vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.d2pc_mono16_to_mono8_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
+                                              ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
     L.d2pc_pipeline_configure.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.d2pc_pipeline_acquire.argtypes = [vp, ctypes.POINTER(FrameDesc), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     L.d2pc_pipeline_submit.argtypes = [vp, ctypes.c_int]
@@ -355,6 +359,26 @@ class Context:
                                         out.ctypes.data, idx.ctypes.data if want_index else None, cap, ctypes.byref(n))
         self._check(st)
         return (out[: n.value], idx[: n.value]) if want_index else out[: n.value]
+
+    def process_mono16(self, image: np.ndarray, median_ksize=11, scale=0.125, want_index=False, capacity=None):
+        """cpp:50-85 for one mono16 frame: device cv_bridge rescale -> median -> x scale -> points."""
+        assert image.dtype == np.uint16 and image.ndim == 2 and image.strides[1] == 2
+        h, w = image.shape
+        cfg = self.config()
+        cap = roi_points(w, h, cfg.border) if capacity is None else capacity
+        out = np.empty((max(cap, 1), 4), dtype=np.float32)
+        idx = np.empty(max(cap, 1), dtype=np.uint32) if want_index else None
+        n = ctypes.c_size_t(0)
+        st = self._L.d2pc_process_mono16(self._h, image.ctypes.data, w, h, image.strides[0], median_ksize, scale,
+                                         out.ctypes.data, idx.ctypes.data if want_index else None, cap, ctypes.byref(n))
+        self._check(st)
+        return (out[: n.value], idx[: n.value]) if want_index else out[: n.value]
+
+    def mono16_to_mono8_device(self, d_src_ptr, width, height, src_row_stride, src_frame_stride, n_frames, d_dst_ptr,
+                               dst_row_stride, dst_frame_stride, stream_ptr=None):
+        self._check(self._L.d2pc_mono16_to_mono8_device(self._h, d_src_ptr, width, height, src_row_stride,
+                                                        src_frame_stride, n_frames, d_dst_ptr, dst_row_stride,
+                                                        dst_frame_stride, stream_ptr))
 
     def median_device(self, d_src_ptr, width, height, src_row_stride, src_frame_stride, n_frames, d_dst_ptr,
                       dst_row_stride, dst_frame_stride, ksize=11, stream_ptr=None):

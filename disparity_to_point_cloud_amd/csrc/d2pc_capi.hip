@@ -60,6 +60,7 @@ struct d2pc_ctx {
   void *d_out = nullptr;     size_t out_cap = 0;
   void *d_idx = nullptr;     size_t idx_cap = 0;
   void *d_med = nullptr;     size_t med_cap = 0;
+  void *d_cvt = nullptr;     size_t cvt_cap = 0;   // mono16 -> mono8 (cpp:50)
   uint32_t *d_counts = nullptr;
   uint32_t *h_counts = nullptr;  // pinned
   // pipelined host path
@@ -388,6 +389,7 @@ int d2pc_destroy(d2pc_ctx *ctx) {
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_idx) (void)hipFree(ctx->d_idx);
   if (ctx->d_med) (void)hipFree(ctx->d_med);
+  if (ctx->d_cvt) (void)hipFree(ctx->d_cvt);
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
   if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
   for (PipeSlot &sl : ctx->slots) {
@@ -593,11 +595,12 @@ int d2pc_debug_read_header(d2pc_ctx *ctx, void *out64) {
 }
 #endif
 
-// Shared body of d2pc_process / d2pc_process_mono8: H2D copy (packed to a
-// 256-byte pitch), optional device median, kernel(s), D2H copy; synchronous.
+// Shared body of d2pc_process / d2pc_process_mono8 / d2pc_process_mono16: H2D copy (packed to a
+// 256-byte pitch), optional cv_bridge mono16 -> mono8 rescale, optional device median, kernel(s),
+// D2H copy; synchronous.  bridge16: `disp` holds uint16 samples that cpp:50 turns into mono8.
 static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int width, int height,
-                              size_t row_stride, int median_ksize, void *out_points, uint32_t *out_index,
-                              size_t capacity, size_t *n_points) {
+                              size_t row_stride, int median_ksize, bool bridge16, void *out_points,
+                              uint32_t *out_index, size_t capacity, size_t *n_points) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
   if (n_points) *n_points = 0;
   if (!disp || !n_points) return fail(ctx, D2PC_ERR_INVALID_ARG, "null argument");
@@ -607,24 +610,27 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
   const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
   if (dtype != D2PC_DTYPE_F32 && dtype != D2PC_DTYPE_U8 && dtype != D2PC_DTYPE_U16)
     return fail(ctx, D2PC_ERR_BAD_DTYPE, "dtype %d is not F32/U8/U16", dtype);
+  const int kdtype = bridge16 ? D2PC_DTYPE_U8 : dtype;  // what the kernels see
   const bool median = median_ksize > 1;
-  if (median && (dtype != D2PC_DTYPE_U8 || !median_ksize_supported(median_ksize)))
+  if (median && (kdtype != D2PC_DTYPE_U8 || !median_ksize_supported(median_ksize)))
     return fail(ctx, D2PC_ERR_INVALID_ARG, "median needs 8-bit input and an odd ksize in 3..11 (got %d)", median_ksize);
-  const size_t es = elem_size(dtype);
-  // device copy of the frame is packed to a 256-byte pitch
+  const size_t es = elem_size(dtype), kes = elem_size(kdtype);
+  // device copies of the frame are packed to a 256-byte pitch
   const size_t pitch = (size_t(width > 0 ? width : 0) * es + 255) & ~size_t(255);
+  const size_t kpitch = (size_t(width > 0 ? width : 0) * kes + 255) & ~size_t(255);
   const int pxt = compact ? ctx->pxt_compact : ctx->pxt_parity;
   Geom g;
-  int st = make_geom(ctx, dtype, scale, width, height, row_stride, 0, 1, 0, pxt, &g);
+  int st = make_geom(ctx, dtype, scale, width, height, row_stride, 0, 1, 0, pxt, &g);  // validates the caller's stride
   if (st != D2PC_OK) return st;
   if (g.roi_n == 0) return D2PC_OK;  // cpp:70,72: empty loops => empty cloud
   if (!out_points) return fail(ctx, D2PC_ERR_INVALID_ARG, "out_points is null");
   if (!compact && capacity < g.roi_n)
     return fail(ctx, D2PC_ERR_CAPACITY, "capacity %zu < %u ROI points", capacity, g.roi_n);
-  // the caller's stride is validated above; the kernel sees the packed copy
-  if ((st = make_geom(ctx, dtype, scale, width, height, pitch, 0, 1, 0, pxt, &g)) != D2PC_OK) return st;
+  // the kernel sees the packed (and, for mono16, rescaled) copy
+  if ((st = make_geom(ctx, kdtype, scale, width, height, kpitch, 0, 1, 0, pxt, &g)) != D2PC_OK) return st;
   if ((st = grow(ctx, &ctx->d_in, &ctx->in_cap, pitch * size_t(height))) != D2PC_OK) return st;
-  if (median && (st = grow(ctx, &ctx->d_med, &ctx->med_cap, pitch * size_t(height))) != D2PC_OK) return st;
+  if (bridge16 && (st = grow(ctx, &ctx->d_cvt, &ctx->cvt_cap, kpitch * size_t(height))) != D2PC_OK) return st;
+  if (median && (st = grow(ctx, &ctx->d_med, &ctx->med_cap, kpitch * size_t(height))) != D2PC_OK) return st;
   if ((st = grow(ctx, &ctx->d_out, &ctx->out_cap, size_t(g.roi_n) * 16)) != D2PC_OK) return st;
   if (out_index && (st = grow(ctx, &ctx->d_idx, &ctx->idx_cap, size_t(g.roi_n) * 4)) != D2PC_OK) return st;
   hipStream_t s = ctx->stream;
@@ -632,15 +638,21 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
   D2PC_HIP(ctx, hipMemcpy2DAsync(ctx->d_in, pitch, disp, row_stride, size_t(width) * es, size_t(height),
                                  hipMemcpyHostToDevice, s));
   const void *kernel_in = ctx->d_in;
+  MedianArgs m;
+  m.width = uint32_t(width);
+  m.height = uint32_t(height);
+  if (bridge16) {
+    m.src_row_stride = uint32_t(pitch);
+    m.dst_row_stride = uint32_t(kpitch);
+    D2PC_HIP(ctx, launch_mono16_to_mono8(ctx->d_in, ctx->d_cvt, m, s));
+    kernel_in = ctx->d_cvt;
+  }
   if (median) {
-    MedianArgs m;
-    m.width = uint32_t(width);
-    m.height = uint32_t(height);
-    m.src_row_stride = m.dst_row_stride = uint32_t(pitch);
-    D2PC_HIP(ctx, launch_median(ctx->d_in, ctx->d_med, m, median_ksize, s));
+    m.src_row_stride = m.dst_row_stride = uint32_t(kpitch);
+    D2PC_HIP(ctx, launch_median(kernel_in, ctx->d_med, m, median_ksize, s));
     kernel_in = ctx->d_med;
   }
-  st = enqueue(ctx, g, kernel_in, dtype, ctx->d_out, out_index ? static_cast<uint32_t *>(ctx->d_idx) : nullptr,
+  st = enqueue(ctx, g, kernel_in, kdtype, ctx->d_out, out_index ? static_cast<uint32_t *>(ctx->d_idx) : nullptr,
                ctx->d_counts, s, true);
   if (st != D2PC_OK) return st;
   size_t n = g.roi_n;
@@ -663,15 +675,54 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
 
 int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale, int width, int height,
                  size_t row_stride, void *out_points, uint32_t *out_index, size_t capacity, size_t *n_points) {
-  return process_host_frame(ctx, disp, dtype, scale, width, height, row_stride, 0, out_points, out_index, capacity,
-                            n_points);
+  return process_host_frame(ctx, disp, dtype, scale, width, height, row_stride, 0, false, out_points, out_index,
+                            capacity, n_points);
 }
 
 int d2pc_process_mono8(d2pc_ctx *ctx, const uint8_t *image, int width, int height, size_t row_stride,
                        int median_ksize, float scale, void *out_points, uint32_t *out_index, size_t capacity,
                        size_t *n_points) {
-  return process_host_frame(ctx, image, D2PC_DTYPE_U8, scale, width, height, row_stride, median_ksize, out_points,
-                            out_index, capacity, n_points);
+  return process_host_frame(ctx, image, D2PC_DTYPE_U8, scale, width, height, row_stride, median_ksize, false,
+                            out_points, out_index, capacity, n_points);
+}
+
+int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int height, size_t row_stride,
+                        int median_ksize, float scale, void *out_points, uint32_t *out_index, size_t capacity,
+                        size_t *n_points) {
+  return process_host_frame(ctx, image, D2PC_DTYPE_U16, scale, width, height, row_stride, median_ksize, true,
+                            out_points, out_index, capacity, n_points);
+}
+
+int d2pc_mono16_to_mono8_device(d2pc_ctx *ctx, const void *d_src, int width, int height, size_t src_row_stride,
+                                size_t src_frame_stride, int n_frames, void *d_dst, size_t dst_row_stride,
+                                size_t dst_frame_stride, void *stream) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!d_src || !d_dst) return fail(ctx, D2PC_ERR_INVALID_ARG, "null device pointer");
+  if (width <= 0 || height <= 0 || n_frames <= 0 || n_frames > 65535)
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "bad size %dx%d x%d", width, height, n_frames);
+  if (src_row_stride < size_t(width) * 2 || src_row_stride % 2 != 0 || dst_row_stride < size_t(width) ||
+      src_row_stride > 0xffffffffull || dst_row_stride > 0xffffffffull || reinterpret_cast<uintptr_t>(d_src) % 2 != 0)
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "bad row stride or alignment (source rows hold %d uint16 samples)", width);
+  const size_t src_extent = size_t(height - 1) * src_row_stride + size_t(width) * 2;
+  const size_t dst_extent = size_t(height - 1) * dst_row_stride + size_t(width);
+  if (n_frames > 1 && (src_frame_stride < src_extent || src_frame_stride % 2 != 0 || dst_frame_stride < dst_extent))
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "frame stride too small");
+  const uintptr_t s0 = reinterpret_cast<uintptr_t>(d_src), d0 = reinterpret_cast<uintptr_t>(d_dst);
+  const uintptr_t s1 = s0 + size_t(n_frames - 1) * src_frame_stride + src_extent;
+  const uintptr_t d1 = d0 + size_t(n_frames - 1) * dst_frame_stride + dst_extent;
+  if (s0 < d1 && d0 < s1) return fail(ctx, D2PC_ERR_INVALID_ARG, "source and destination overlap");
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  MedianArgs m;
+  m.width = uint32_t(width);
+  m.height = uint32_t(height);
+  m.n_frames = uint32_t(n_frames);
+  m.src_row_stride = uint32_t(src_row_stride);
+  m.dst_row_stride = uint32_t(dst_row_stride);
+  m.src_frame_stride = n_frames > 1 ? src_frame_stride : 0;
+  m.dst_frame_stride = n_frames > 1 ? dst_frame_stride : 0;
+  D2PC_HIP(ctx, launch_mono16_to_mono8(d_src, d_dst, m, static_cast<hipStream_t>(stream)));
+  return D2PC_OK;
 }
 
 int d2pc_median_device(d2pc_ctx *ctx, const void *d_src, int width, int height, size_t src_row_stride,

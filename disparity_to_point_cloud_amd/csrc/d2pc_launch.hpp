@@ -38,6 +38,8 @@ struct MedianArgs {
 };
 bool median_ksize_supported(int k);
 hipError_t launch_median(const void *src, void *dst, const MedianArgs &a, int ksize, hipStream_t stream);
+// cv_bridge mono16 -> mono8 (d2pc_median.hip); strides in bytes, src rows hold uint16
+hipError_t launch_mono16_to_mono8(const void *src, void *dst, const MedianArgs &a, hipStream_t stream);
 
 // Depth-map fusion inner loop (d2pc_fusion.hip): rule + combined confidence +
 // 3x3 median + crop.  Rules are numbered as in include/d2pc.h (source order of

@@ -98,20 +98,29 @@ class Disparity2PCloudT {
     //            on the host (Msgs::prepare(msg, 11): cv_bridge + OpenCV in the
     //            ROS build, image_prep.hpp in the ROS-free one), or on the
     //            device inside d2pc_process_mono8 (then prepare only decodes)
-    Mono8 median_filtered = Msgs::prepare(*msg, gpu_median_ ? 1 : 11);
+    // A little-endian mono16 image goes to the device as it is: cpp:50's rescale to mono8
+    // (convertTo(CV_8U, 255./65535.)) runs there too, in front of the median.
+    const bool raw16 = gpu_median_ && msg->encoding == "mono16" && !msg->is_bigendian &&
+                       msg->step >= 2 * msg->width && msg->data.size() >= size_t(msg->step) * msg->height;
+    Mono8 median_filtered;
+    if (!raw16) median_filtered = Msgs::prepare(*msg, gpu_median_ ? 1 : 11);
     if (verbose_) printf("medianBlur \n");
 
     // cpp:60-85: convertTo(CV_32FC1, 1/8) + reprojectImageTo3D + ROI loop +
     // toROSMsg -- one C-ABI call, writing straight into output.data
     PointCloud2 output;
-    const size_t cap = d2pc_roi_points(median_filtered.width, median_filtered.height, 40);
+    const int width = raw16 ? int(msg->width) : median_filtered.width;
+    const int height = raw16 ? int(msg->height) : median_filtered.height;
+    const size_t cap = d2pc_roi_points(width, height, 40);
     output.data.resize(cap * 16);
     size_t n = 0;
-    const int st = d2pc_process_mono8(ctx_, median_filtered.pix.data(), median_filtered.width, median_filtered.height,
-                                      size_t(median_filtered.width), gpu_median_ ? 11 : 0, 1.0f / 8.0f,
-                                      output.data.data(), nullptr, cap, &n);
+    const int st =
+        raw16 ? d2pc_process_mono16(ctx_, reinterpret_cast<const uint16_t *>(msg->data.data()), width, height,
+                                    size_t(msg->step), 11, 1.0f / 8.0f, output.data.data(), nullptr, cap, &n)
+              : d2pc_process_mono8(ctx_, median_filtered.pix.data(), width, height, size_t(width),
+                                   gpu_median_ ? 11 : 0, 1.0f / 8.0f, output.data.data(), nullptr, cap, &n);
     if (st != D2PC_OK)
-      throw std::runtime_error(std::string("d2pc_process_mono8: ") + d2pc_status_string(st) + ": " +
+      throw std::runtime_error(std::string("d2pc_process_mono8/16: ") + d2pc_status_string(st) + ": " +
                                d2pc_last_error(ctx_));
     output.data.resize(n * 16);
     if (verbose_) printf("Cloud size: %zu\n", n);  // cpp:82

@@ -190,6 +190,17 @@ int d2pc_median_device(d2pc_ctx *ctx, const void *d_src, int width, int height,
                        size_t dst_frame_stride_bytes, int ksize, void *stream);
 
 /*
+ * cv_bridge::toCvCopy(msg, "mono8") applied to a mono16 image (cpp:50) on the
+ * device: dst = saturate(round_half_even(src * (float)(255./65535.))), i.e.
+ * cv::Mat::convertTo(CV_8U, 255./65535.).  src rows hold uint16 samples (strides
+ * in bytes, 2-byte aligned); asynchronous on `stream`; src and dst must not overlap.
+ */
+int d2pc_mono16_to_mono8_device(d2pc_ctx *ctx, const void *d_src, int width, int height,
+                                size_t src_row_stride_bytes, size_t src_frame_stride_bytes,
+                                int n_frames, void *d_dst, size_t dst_row_stride_bytes,
+                                size_t dst_frame_stride_bytes, void *stream);
+
+/*
  * cpp:55-85 in one call for one mono8 frame in HOST memory (what
  * cv_bridge::toCvCopy(msg,"mono8") returned, cpp:50): median (median_ksize,
  * the reference uses 11; 0 or 1 = none) -> x scale (1/8, cpp:61) ->
@@ -200,6 +211,14 @@ int d2pc_process_mono8(d2pc_ctx *ctx, const uint8_t *image, int width, int heigh
                        size_t row_stride_bytes, int median_ksize, float scale,
                        void *out_points, uint32_t *out_index,
                        size_t capacity_points, size_t *n_points);
+
+/* The same for a mono16 frame (what the node receives when the disparity is
+ * published as 16-bit): cpp:50's cv_bridge rescale to mono8 runs on the device
+ * in front of the median.  2 bytes per pixel cross PCIe on the way in. */
+int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int height,
+                        size_t row_stride_bytes, int median_ksize, float scale,
+                        void *out_points, uint32_t *out_index,
+                        size_t capacity_points, size_t *n_points);
 
 /*
  * Pipelined host path: up to `depth`

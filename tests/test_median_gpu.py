@@ -80,3 +80,49 @@ def test_process_mono8_is_the_callback_body(mode):
     want_raw = (oracle.reproject(img, q, border=40, scale=0.125) if mode == d2pc.MODE_PARITY
                 else oracle.reproject_compact(img, q, border=40, scale=0.125)[0])
     assert_points_close(raw, want_raw, max_ulp=1)
+
+
+# ---- cv_bridge mono16 -> mono8 on the device (cpp:50) -----------------------------
+@pytest.mark.parametrize("w,h", [(640, 480), (752, 480), (1, 1), (3, 5), (5, 3), (129, 7), (1000, 3)])
+def test_mono16_to_mono8_device_matches_oracle(w, h):
+    rng = np.random.default_rng(w * 31 + h)
+    imgs = np.stack([rng.integers(0, 65536, size=(h, w)).astype(np.uint16),
+                     (rng.integers(0, 256, size=(h, w)) * 257).astype(np.uint16)])    # exact multiples: k*257 -> k
+    imgs[0].flat[: min(imgs[0].size, 8)] = [0, 128, 129, 385, 65535, 65407, 65406, 32896][: min(imgs[0].size, 8)]  # .5 ties
+    src = torch.from_numpy(imgs.view(np.int16)).cuda()
+    dst = torch.full((2, h, w + 3), 7, dtype=torch.uint8, device="cuda")
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        ctx.mono16_to_mono8_device(src.data_ptr(), w, h, 2 * w, 2 * w * h, 2, dst.data_ptr(), w + 3, (w + 3) * h,
+                                   torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        for f in range(2):
+            assert np.array_equal(got[f, :, :w], oracle.mono16_to_mono8(imgs[f]))
+            assert (got[f, :, w:] == 7).all()
+        with pytest.raises(d2pc.D2pcError):
+            ctx.mono16_to_mono8_device(src.data_ptr(), w, h, 2 * w - 1 if w > 1 else 1, 0, 1, dst.data_ptr(), w + 3, 0)
+        with pytest.raises(d2pc.D2pcError):
+            ctx.mono16_to_mono8_device(src.data_ptr(), w, h, 2 * w, 0, 1, src.data_ptr(), w, 0)
+
+
+@pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
+@pytest.mark.parametrize("k", [0, 11])
+def test_process_mono16_is_the_whole_callback(mode, k):
+    """cpp:50-85 for a mono16 frame: rescale, median, x 1/8, reproject -- all on the device."""
+    from helpers import synth_disparity
+    q = d2pc.make_q()
+    rng = np.random.default_rng(k + mode)
+    for img in (synth_disparity(1, 0, 640, 480, "mono16"), rng.integers(0, 65536, size=(131, 203)).astype(np.uint16)):
+        m8 = oracle.mono16_to_mono8(img)
+        filt = oracle.median_u8(m8, k) if k else m8
+        with d2pc.Context(q=q, mode=mode) as ctx:
+            if mode == d2pc.MODE_PARITY:
+                got = ctx.process_mono16(img, median_ksize=k)
+                assert_points_close(got, oracle.reproject(filt, q, border=40, scale=0.125), max_ulp=1)
+            else:
+                gp, gi = ctx.process_mono16(img, median_ksize=k, want_index=True)
+                wp, wi = oracle.reproject_compact(filt, q, border=40, scale=0.125)
+                assert np.array_equal(gi, wi)
+                assert_points_close(gp, wp, max_ulp=1)
+            with pytest.raises(d2pc.D2pcError):
+                ctx.process_mono16(img, median_ksize=4)
