@@ -1,7 +1,7 @@
 // replay_main.cpp -- ROS-free harness around Disparity2PCloud::DisparityCb.
 //   d2pc_replay prep  <in.raw> <w> <h> <mono8|mono16> <out.raw>
 //        host plumbing only (toCvCopy + medianBlur 11): no GPU needed
-//   d2pc_replay cloud <in.raw> <w> <h> <mono8|mono16> <out.bin> [compact] [hostmedian] [name=value ...]
+//   d2pc_replay cloud <in.raw> <w> <h> <mono8|mono16> <out.bin> [compact] [hostmedian] [step=N] [bigendian] [name=value ...]
 //        name=value sets a private parameter (~fx_ ~fy_ ~cx_ ~cy_ ~base_line_), as a launch file would
 //        full callback; writes PointCloud2 metadata (text) then the payload
 // <in.raw> holds the sensor_msgs/Image data bytes (row-major, step = w*bpp).
@@ -35,6 +35,9 @@ int main(int argc, char **argv) {
   img->height = uint32_t(atoi(argv[4]));
   img->encoding = enc;
   img->step = img->width * (enc == "mono16" ? 2u : 1u);
+  for (int i = 7; i < argc; ++i)  // step=<bytes>: padded rows; bigendian: byte-swapped 16-bit samples
+    if (!strncmp(argv[i], "step=", 5)) img->step = uint32_t(atoi(argv[i] + 5));
+  img->is_bigendian = has_flag(argc, argv, "bigendian") ? 1 : 0;
   img->data = slurp(argv[2]);
   img->header.stamp.sec = 1234;
   img->header.stamp.nsec = 5678;
@@ -51,7 +54,7 @@ int main(int argc, char **argv) {
       d2pc::ParamSource nh;  // d2pcloud.launch sets no params: defaults apply
       for (int i = 7; i < argc; ++i) {
         const char *eq = strchr(argv[i], '=');
-        if (eq) nh.values[std::string(argv[i], size_t(eq - argv[i]))] = atof(eq + 1);
+        if (eq && strncmp(argv[i], "step=", 5)) nh.values[std::string(argv[i], size_t(eq - argv[i]))] = atof(eq + 1);
       }
       d2pc::Disparity2PCloudT<d2pc_shim::Msgs> node(
           nh, [&](const d2pc_shim::PointCloud2 &pc) { got = pc; ++published; }, 0, nullptr,

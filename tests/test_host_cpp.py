@@ -118,3 +118,36 @@ def test_private_parameters_reach_the_calibration(replay, tmp_path):
     q = d2pc.make_q(nx=752, ny=480, **params)  # hpp:101-103: rectification size stays 752x480
     want = oracle.reproject(oracle.median_u8(img, 11), q, border=40, scale=0.125)
     assert_points_close(pts, want, max_ulp=1, rel=1e-5, what="custom calibration")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["padded_step", "bigendian", "padded_bigendian_hostmedian"])
+def test_mono16_message_layouts(replay, tmp_path, variant):
+    """A little-endian mono16 message goes to the device raw (d2pc_process_mono16, any row step); a big-endian one
+    is decoded on the host like cv_bridge would.  Arbitrary 16-bit values: the rescale's rounding matters."""
+    import disparity_to_point_cloud_amd as d2pc
+
+    rng = np.random.default_rng(len(variant))
+    img = rng.integers(0, 65536, size=(150, 217)).astype(np.uint16)
+    w = img.shape[1]
+    extra, wire = [], img
+    if "padded" in variant:
+        step = 2 * w + 14
+        extra.append(f"step={step}")
+        wire = np.zeros((img.shape[0], step // 2), dtype=np.uint16)
+        wire[:, :w] = img
+        wire[:, w:] = 0xABCD
+    if "bigendian" in variant:
+        extra.append("bigendian")
+        wire = wire.byteswap()
+    if "hostmedian" in variant:
+        extra.append("hostmedian")
+    src, dst = tmp_path / "in.raw", tmp_path / "out.bin"
+    src.write_bytes(np.ascontiguousarray(wire).tobytes())
+    p = subprocess.run([replay, "cloud", str(src), str(w), str(img.shape[0]), "mono16", str(dst), *extra],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    _, payload = dst.read_bytes().split(b"\n", 1)
+    pts = np.frombuffer(payload, dtype=np.float32).reshape(-1, 4)
+    med = oracle.median_u8(oracle.mono16_to_mono8(img), 11)
+    assert_points_close(pts, oracle.reproject(med, d2pc.make_q(), border=40, scale=0.125), max_ulp=1, what=variant)
