@@ -13,6 +13,7 @@ from .capi import (  # noqa: F401
     DTYPE_F32,
     DTYPE_U8,
     DTYPE_U16,
+    DTYPE_MONO16,
     MODE_PARITY,
     MODE_COMPACT,
     CALIB_BLOB_BYTES,

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libd2pc.so"
 
-DTYPE_F32, DTYPE_U8, DTYPE_U16 = 0, 1, 2
+DTYPE_F32, DTYPE_U8, DTYPE_U16, DTYPE_MONO16 = 0, 1, 2, 3
 MODE_PARITY, MODE_COMPACT = 0, 1
 CALIB_BLOB_BYTES = 136
 
@@ -400,10 +400,12 @@ class Context:
     def pipeline_configure(self, depth=3, direct_host_write=False):
         self._check(self._L.d2pc_pipeline_configure(self._h, depth, int(direct_host_write)))
 
-    def pipeline_submit(self, image: np.ndarray, scale=1.0, median_ksize=0, want_index=False, tag=0) -> int:
+    def pipeline_submit(self, image: np.ndarray, scale=1.0, median_ksize=0, want_index=False, tag=0,
+                        mono16=False) -> int:
         """Acquire a slot, copy `image` into its pinned input buffer (a real
-        producer would decode straight into it) and submit.  Returns the slot."""
-        dt = _NP2DT[image.dtype]
+        producer would decode straight into it) and submit.  Returns the slot.
+        mono16: a uint16 image that cv_bridge would rescale to mono8 first (DTYPE_MONO16)."""
+        dt = DTYPE_MONO16 if mono16 else _NP2DT[image.dtype]
         h, w = image.shape
         desc = FrameDesc(dt, scale, w, h, w * image.itemsize, median_ksize, int(want_index), tag)
         host_in, slot = ctypes.c_void_p(), ctypes.c_int()

@@ -26,6 +26,7 @@ struct PipeSlot {
   uint32_t *h_count = nullptr;                       // pinned
   void *d_in = nullptr;      size_t d_in_cap = 0;
   void *d_med = nullptr;     size_t d_med_cap = 0;
+  void *d_cvt = nullptr;     size_t d_cvt_cap = 0;   // MONO16 frames rescaled to 8 bits
   void *d_out = nullptr;     size_t d_out_cap = 0;
   void *d_idx = nullptr;     size_t d_idx_cap = 0;
   void *d_state = nullptr;   size_t d_state_cap = 0;
@@ -399,6 +400,7 @@ int d2pc_destroy(d2pc_ctx *ctx) {
     if (sl.h_count) (void)hipHostFree(sl.h_count);
     if (sl.d_in) (void)hipFree(sl.d_in);
     if (sl.d_med) (void)hipFree(sl.d_med);
+    if (sl.d_cvt) (void)hipFree(sl.d_cvt);
     if (sl.d_out) (void)hipFree(sl.d_out);
     if (sl.d_idx) (void)hipFree(sl.d_idx);
     if (sl.d_state) (void)hipFree(sl.d_state);
@@ -608,8 +610,12 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
   const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
+  if (dtype == D2PC_DTYPE_MONO16) {
+    bridge16 = true;
+    dtype = D2PC_DTYPE_U16;  // layout of the caller's buffer
+  }
   if (dtype != D2PC_DTYPE_F32 && dtype != D2PC_DTYPE_U8 && dtype != D2PC_DTYPE_U16)
-    return fail(ctx, D2PC_ERR_BAD_DTYPE, "dtype %d is not F32/U8/U16", dtype);
+    return fail(ctx, D2PC_ERR_BAD_DTYPE, "dtype %d is not F32/U8/U16/MONO16", dtype);
   const int kdtype = bridge16 ? D2PC_DTYPE_U8 : dtype;  // what the kernels see
   const bool median = median_ksize > 1;
   if (median && (kdtype != D2PC_DTYPE_U8 || !median_ksize_supported(median_ksize)))
@@ -689,7 +695,7 @@ int d2pc_process_mono8(d2pc_ctx *ctx, const uint8_t *image, int width, int heigh
 int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int height, size_t row_stride,
                         int median_ksize, float scale, void *out_points, uint32_t *out_index, size_t capacity,
                         size_t *n_points) {
-  return process_host_frame(ctx, image, D2PC_DTYPE_U16, scale, width, height, row_stride, median_ksize, true,
+  return process_host_frame(ctx, image, D2PC_DTYPE_MONO16, scale, width, height, row_stride, median_ksize, true,
                             out_points, out_index, capacity, n_points);
 }
 
@@ -794,11 +800,13 @@ int d2pc_pipeline_acquire(d2pc_ctx *ctx, const d2pc_frame_desc *desc, void **hos
   if (ctx->pipe_depth == 0) return fail(ctx, D2PC_ERR_INVALID_ARG, "call d2pc_pipeline_configure first");
   if (!ctx->have_q) return fail(ctx, D2PC_ERR_NOT_CALIBRATED, "Q matrix not set");
   const bool median = desc->median_ksize > 1;
-  if (median && (desc->dtype != D2PC_DTYPE_U8 || !median_ksize_supported(desc->median_ksize)))
-    return fail(ctx, D2PC_ERR_INVALID_ARG, "median needs 8-bit input and an odd ksize in 3..11");
+  const bool bridge16 = desc->dtype == D2PC_DTYPE_MONO16;  // cpp:50's rescale to 8 bits runs on the device
+  if (median && ((desc->dtype != D2PC_DTYPE_U8 && !bridge16) || !median_ksize_supported(desc->median_ksize)))
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "median needs 8-bit (or MONO16) input and an odd ksize in 3..11");
   DeviceGuard guard(ctx->device);
-  Geom g;  // validates dtype / size / stride
-  int st = make_geom(ctx, desc->dtype, desc->scale, desc->width, desc->height, desc->row_stride_bytes, 0, 1, 0,
+  Geom g;  // validates dtype / size / stride of the caller's layout
+  int st = make_geom(ctx, bridge16 ? int(D2PC_DTYPE_U16) : desc->dtype, desc->scale, desc->width, desc->height,
+                     desc->row_stride_bytes, 0, 1, 0,
                      ctx->cfg.mode == D2PC_MODE_COMPACT ? ctx->pxt_compact : ctx->pxt_parity, &g);
   if (st != D2PC_OK) return st;
   int found = -1;
@@ -813,7 +821,10 @@ int d2pc_pipeline_acquire(d2pc_ctx *ctx, const d2pc_frame_desc *desc, void **hos
   const size_t in_bytes = size_t(desc->height) * desc->row_stride_bytes;
   if ((st = grow_pinned(ctx, &sl.h_in, &sl.h_in_cap, in_bytes)) != D2PC_OK) return st;
   if ((st = grow(ctx, &sl.d_in, &sl.d_in_cap, in_bytes)) != D2PC_OK) return st;
-  if (median && (st = grow(ctx, &sl.d_med, &sl.d_med_cap, in_bytes)) != D2PC_OK) return st;
+  // MONO16: the 8-bit copy (and its median) have their own 256-byte pitch
+  const size_t k_bytes = bridge16 ? size_t(desc->height) * ((size_t(desc->width) + 255) & ~size_t(255)) : in_bytes;
+  if (bridge16 && (st = grow(ctx, &sl.d_cvt, &sl.d_cvt_cap, k_bytes)) != D2PC_OK) return st;
+  if (median && (st = grow(ctx, &sl.d_med, &sl.d_med_cap, k_bytes)) != D2PC_OK) return st;
   sl.roi_n = g.roi_n;
   sl.idx_off = (size_t(g.roi_n) * 16 + 255) & ~size_t(255);
   const size_t out_bytes = sl.idx_off + (desc->want_index ? size_t(g.roi_n) * 4 : 0) + 256;
@@ -837,8 +848,11 @@ int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
   PipeSlot &sl = ctx->slots[slot];
   const d2pc_frame_desc &d = sl.desc;
   const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
+  const bool bridge16 = d.dtype == D2PC_DTYPE_MONO16;
+  const int kdtype = bridge16 ? int(D2PC_DTYPE_U8) : d.dtype;  // what the kernels see
+  const size_t kstride = bridge16 ? (size_t(d.width) + 255) & ~size_t(255) : d.row_stride_bytes;
   Geom g;
-  int st = make_geom(ctx, d.dtype, d.scale, d.width, d.height, d.row_stride_bytes, 0, 1, 0,
+  int st = make_geom(ctx, kdtype, d.scale, d.width, d.height, kstride, 0, 1, 0,
                      compact ? ctx->pxt_compact : ctx->pxt_parity, &g);
   if (st != D2PC_OK) return st;
   // the slot's buffers were sized at acquire time: a d2pc_set_border in between must not overflow them
@@ -849,12 +863,18 @@ int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
   const size_t in_bytes = size_t(d.height) * d.row_stride_bytes;
   D2PC_HIP(ctx, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, s));
   const void *kin = sl.d_in;
+  MedianArgs m;
+  m.width = uint32_t(d.width);
+  m.height = uint32_t(d.height);
+  if (bridge16) {
+    m.src_row_stride = uint32_t(d.row_stride_bytes);
+    m.dst_row_stride = uint32_t(kstride);
+    D2PC_HIP(ctx, launch_mono16_to_mono8(sl.d_in, sl.d_cvt, m, s));
+    kin = sl.d_cvt;
+  }
   if (d.median_ksize > 1) {
-    MedianArgs m;
-    m.width = uint32_t(d.width);
-    m.height = uint32_t(d.height);
-    m.src_row_stride = m.dst_row_stride = uint32_t(d.row_stride_bytes);
-    D2PC_HIP(ctx, launch_median(sl.d_in, sl.d_med, m, d.median_ksize, s));
+    m.src_row_stride = m.dst_row_stride = uint32_t(kstride);
+    D2PC_HIP(ctx, launch_median(kin, sl.d_med, m, d.median_ksize, s));
     kin = sl.d_med;
   }
   sl.h_count[0] = 0;
@@ -865,7 +885,7 @@ int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
     uint32_t *kidx = !d.want_index ? nullptr
                      : ctx->pipe_direct ? reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(sl.h_out) + sl.idx_off)
                                         : static_cast<uint32_t *>(sl.d_idx);
-    st = enqueue(ctx, g, kin, d.dtype, kout, kidx, sl.d_count, s, true, &sl.d_state, &sl.d_state_cap);
+    st = enqueue(ctx, g, kin, kdtype, kout, kidx, sl.d_count, s, true, &sl.d_state, &sl.d_state_cap);
     if (st != D2PC_OK) return st;
     D2PC_HIP(ctx, hipMemcpyAsync(sl.h_count, sl.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (!ctx->pipe_direct) {

@@ -49,7 +49,15 @@ typedef enum d2pc_status {
  * F32 is the reference's `real_disparity` (CV_32FC1, cpp:60-61).
  * U8/U16 fuse the reference's convertTo(CV_32FC1, scale) (cpp:61) into the
  * kernel: d = (float)raw * scale in fp32 (scale = 1/8 in the reference). */
-typedef enum d2pc_dtype { D2PC_DTYPE_F32 = 0, D2PC_DTYPE_U8 = 1, D2PC_DTYPE_U16 = 2 } d2pc_dtype;
+typedef enum d2pc_dtype {
+  D2PC_DTYPE_F32 = 0,
+  D2PC_DTYPE_U8 = 1,
+  D2PC_DTYPE_U16 = 2,       /* raw 16-bit disparities, decoded as (float)v * scale                     */
+  D2PC_DTYPE_MONO16 = 3     /* HOST entry points only (d2pc_process, d2pc_pipeline_*): a 16-bit image that
+                               cv_bridge::toCvCopy(msg,"mono8") rescales to 8 bits first (cpp:50:
+                               convertTo(CV_8U, 255./65535.)); the rescale runs on the device and the
+                               frame continues as U8 (median allowed).  d2pc_process_mono16 = this. */
+} d2pc_dtype;
 
 typedef enum d2pc_mode {
   /* What the reference publishes (cpp:70-81): every ROI pixel, row-major,
@@ -233,7 +241,7 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
  * i-1 overlap.  Frames are collected in submission order.
  */
 typedef struct d2pc_frame_desc {
-  int32_t dtype;             /* d2pc_dtype */
+  int32_t dtype;             /* d2pc_dtype (MONO16 allowed) */
   float scale;               /* U8/U16 decode scale (cpp:61: 1/8) */
   int32_t width, height;
   size_t row_stride_bytes;   /* layout of the pinned input buffer */

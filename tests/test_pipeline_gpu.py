@@ -111,3 +111,35 @@ def test_border_change_between_acquire_and_submit_is_refused():
         p, _, tag, _ = ctx.pipeline_collect()
         assert tag == 6
         assert_points_close(p, oracle.reproject(fr, q, border=0), max_ulp=1)
+
+
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
+def test_pipeline_mono16_frames_are_rescaled_on_the_device(mode, direct):
+    """DTYPE_MONO16: cpp:50's cv_bridge rescale, the median and the reprojection all run on the slot's stream."""
+    q = d2pc.make_q()
+    rng = np.random.default_rng(3)
+    imgs = [synth_disparity(1, 0, 640, 480, "mono16"), rng.integers(0, 65536, size=(133, 201)).astype(np.uint16),
+            rng.integers(0, 65536, size=(480, 752)).astype(np.uint16)]
+    ks = [11, 0, 11]
+    with d2pc.Context(q=q, mode=mode) as ctx:
+        ctx.pipeline_configure(depth=2, direct_host_write=direct)
+        got = []
+        for i, (img, k) in enumerate(zip(imgs, ks)):
+            if i >= 2:
+                got.append(ctx.pipeline_collect())
+            ctx.pipeline_submit(img, scale=0.125, median_ksize=k, want_index=True, tag=i, mono16=True)
+        while len(got) < len(imgs):
+            got.append(ctx.pipeline_collect())
+        with pytest.raises(d2pc.D2pcError):
+            ctx.pipeline_submit(imgs[1], median_ksize=4, mono16=True)
+    for i, (p, idx, tag, _) in enumerate(got):
+        assert tag == i
+        m8 = oracle.mono16_to_mono8(imgs[i])
+        filt = oracle.median_u8(m8, ks[i]) if ks[i] else m8
+        if mode == d2pc.MODE_PARITY:
+            assert_points_close(p, oracle.reproject(filt, q, border=40, scale=0.125), max_ulp=1, what=f"frame {i}")
+        else:
+            wp, wi = oracle.reproject_compact(filt, q, border=40, scale=0.125)
+            assert np.array_equal(idx, wi)
+            assert_points_close(p, wp, max_ulp=1, what=f"frame {i}")
