@@ -223,7 +223,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   // default (0): the single pass (one read of the input) wins once a launch is big enough to amortise
   // its pipeline fill -- measured crossover ~25k tiles (16 x 4K: 449 vs 495 us; 32 x 1080p: 196 vs 207;
   // 256 x 752x480: 278 vs 290; but 8 x 1080p: 68 vs 61) -- and needs a few frames in flight, because a
-  // frame's ticket word serialises at ~18 ns per tile (one 4K frame: 72 vs 44 us)
+  // frame's ticket word serialises at ~18 ns per tile (one 4K frame: 72 vs 35 us)
   const bool big_batch = g.n_frames >= 4 && g.total_tiles >= 24576;
   a.compact_algo = ctx->cfg.compact_algo ? ctx->cfg.compact_algo : (big_batch ? 2 : 1);
   ctx->last_compact_algo = a.compact_algo;
