@@ -107,6 +107,66 @@ def cpu_baseline(q, border, budget_s=12.0):
     }
 
 
+def host_path_rates(q, border):
+    """PCIe-inclusive rates of the host entry points for one 4K fp32 frame (never the headline): the
+    synchronous d2pc_process on pageable buffers, and the pipelined path (depth 3, pinned staging,
+    kernels storing straight into pinned host memory)."""
+    import ctypes
+    import time
+    from disparity_to_point_cloud_amd.capi import FrameDesc
+    L = d2pc.load_library()
+    fr = synth_disparity(4, 0, W4K, H4K, "uniform")
+    cap = d2pc.roi_points(W4K, H4K, border)
+    res = {}
+    with d2pc.Context(q=q, border=border) as ctx:
+        out = np.empty((cap, 4), dtype=np.float32)
+        n = ctypes.c_size_t()
+
+        def once():
+            st = L.d2pc_process(ctx.handle, fr.ctypes.data, 0, 1.0, W4K, H4K, fr.strides[0], out.ctypes.data, None, cap,
+                                ctypes.byref(n))
+            assert st == 0, st
+        for _ in range(2):
+            once()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.5:
+            once()
+            k += 1
+        dt = (time.perf_counter() - t0) / k
+        res["sync_d2pc_process"] = {"ms_per_frame": round(dt * 1e3, 3), "Mpixels_per_s": round(W4K * H4K / dt / 1e6, 1),
+                                    "pcie_GBs": round((fr.nbytes + n.value * 16) / dt / 1e9, 1)}
+    with d2pc.Context(q=q, border=border) as ctx:
+        ctx.pipeline_configure(depth=3, direct_host_write=True)
+        desc = FrameDesc(0, 1.0, W4K, H4K, W4K * 4, 0, 0, 0)
+        filled = set()
+
+        def submit():
+            hin, slot = ctypes.c_void_p(), ctypes.c_int()
+            assert L.d2pc_pipeline_acquire(ctx.handle, ctypes.byref(desc), ctypes.byref(hin), ctypes.byref(slot)) == 0
+            if slot.value not in filled:  # a producer decodes straight into the pinned slot; not part of this path
+                ctypes.memmove(hin, fr.ctypes.data, fr.nbytes)
+                filled.add(slot.value)
+            assert L.d2pc_pipeline_submit(ctx.handle, slot.value) == 0
+
+        def collect():
+            slot, pts, m = ctypes.c_int(), ctypes.c_void_p(), ctypes.c_size_t()
+            assert L.d2pc_pipeline_collect(ctx.handle, ctypes.byref(slot), ctypes.byref(pts), None, ctypes.byref(m), None) == 0
+            L.d2pc_pipeline_release(ctx.handle, slot.value)
+        submit()
+        submit()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.5:
+            submit()
+            collect()
+            k += 1
+        dt = (time.perf_counter() - t0) / k
+        collect()
+        collect()
+        res["pipelined_direct_host_write"] = {"ms_per_frame": round(dt * 1e3, 3),
+                                              "Mpixels_per_s": round(W4K * H4K / dt / 1e6, 1)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +301,7 @@ def main():
             "kernel_ms_avg": round(kms, 4), "what": "fused cpp:61 decode: 1 B read + 16 B written per pixel"}
         del b3
         c3.close()
+        variants["host_path_pcie_inclusive_1x4K_parity"] = host_path_rates(q, a.border)
         out["variants_1gpu"] = variants
     if rank == 0 and world == 1 and not a.no_cpu:  # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(q, a.border)
