@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "d2pc_check_async_error", "d2pc_set_tuning", "d2pc_median_device", "d2pc_process_mono8",
     "d2pc_pipeline_configure", "d2pc_pipeline_acquire", "d2pc_pipeline_submit", "d2pc_pipeline_collect",
     "d2pc_pipeline_release", "d2pc_fuse_desc_init", "d2pc_fuse_device", "d2pc_crop_to_square",
-    "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16",
+    "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16", "d2pc_last_stage_times",
 ]
 # d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
 (FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
@@ -74,6 +74,11 @@ class FuseDesc(ctypes.Structure):
         ("fused", ctypes.c_void_p), ("fused_pitch", ctypes.c_size_t), ("fused_frame_stride", ctypes.c_size_t),
         ("combined", ctypes.c_void_p), ("combined_pitch", ctypes.c_size_t), ("combined_frame_stride", ctypes.c_size_t),
     ]
+
+
+class StageTimes(ctypes.Structure):
+    _fields_ = [("h2d_ms", ctypes.c_float), ("prep_ms", ctypes.c_float), ("kernel_ms", ctypes.c_float),
+                ("d2h_ms", ctypes.c_float), ("total_ms", ctypes.c_float)]
 
 
 class D2pcError(RuntimeError):
@@ -145,6 +150,7 @@ def load_library():
                                       vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.d2pc_mono16_to_mono8_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
                                               ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
+    L.d2pc_last_stage_times.argtypes = [vp, ctypes.POINTER(StageTimes)]
     L.d2pc_pipeline_configure.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.d2pc_pipeline_acquire.argtypes = [vp, ctypes.POINTER(FrameDesc), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     L.d2pc_pipeline_submit.argtypes = [vp, ctypes.c_int]
@@ -379,6 +385,12 @@ class Context:
         self._check(self._L.d2pc_mono16_to_mono8_device(self._h, d_src_ptr, width, height, src_row_stride,
                                                         src_frame_stride, n_frames, d_dst_ptr, dst_row_stride,
                                                         dst_frame_stride, stream_ptr))
+
+    def last_stage_times(self) -> dict:
+        """Times of the last synchronous host call made with set_tuning("stage_timing", 1)."""
+        t = StageTimes()
+        self._check(self._L.d2pc_last_stage_times(self._h, ctypes.byref(t)))
+        return {k: getattr(t, k) for k, _ in StageTimes._fields_}
 
     def median_device(self, d_src_ptr, width, height, src_row_stride, src_frame_stride, n_frames, d_dst_ptr,
                       dst_row_stride, dst_frame_stride, ksize=11, stream_ptr=None):

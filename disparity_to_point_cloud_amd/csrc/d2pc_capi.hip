@@ -54,6 +54,10 @@ struct d2pc_ctx {
   int last_compact_algo = 0;  // what the last COMPACT launch used
   int force_general_q = 0;
   int no_vec_rows = 0;
+  int stage_timing = 0;          // record per-stage HIP events in the synchronous host entry points
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  d2pc_stage_times times{};
+  bool have_times = false;
   int fuse_rows = 0;             // d2pc_fuse_device rows per wave: 0 = choose, else 2..1024
   // device scratch
   void *d_state = nullptr;   size_t state_cap = 0;
@@ -408,6 +412,8 @@ int d2pc_destroy(d2pc_ctx *ctx) {
     if (sl.done) (void)hipEventDestroy(sl.done);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
+  for (hipEvent_t e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return D2PC_OK;
@@ -537,6 +543,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 1 && value <= 64) ctx->onepass_blocks_per_cu = value;
   else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
+  else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
   return D2PC_OK;
@@ -641,8 +648,16 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
   if (out_index && (st = grow(ctx, &ctx->d_idx, &ctx->idx_cap, size_t(g.roi_n) * 4)) != D2PC_OK) return st;
   hipStream_t s = ctx->stream;
   SyncOnExit drain(s);
+  const bool timing = ctx->stage_timing != 0;
+  ctx->have_times = false;
+  if (timing)
+    for (hipEvent_t &e : ctx->ev)
+      if (!e) D2PC_HIP(ctx, hipEventCreate(&e));
+  auto mark = [&](int i) { return timing ? hipEventRecord(ctx->ev[i], s) : hipSuccess; };
+  D2PC_HIP(ctx, mark(0));
   D2PC_HIP(ctx, hipMemcpy2DAsync(ctx->d_in, pitch, disp, row_stride, size_t(width) * es, size_t(height),
                                  hipMemcpyHostToDevice, s));
+  D2PC_HIP(ctx, mark(1));
   const void *kernel_in = ctx->d_in;
   MedianArgs m;
   m.width = uint32_t(width);
@@ -658,9 +673,11 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
     D2PC_HIP(ctx, launch_median(kernel_in, ctx->d_med, m, median_ksize, s));
     kernel_in = ctx->d_med;
   }
+  D2PC_HIP(ctx, mark(2));
   st = enqueue(ctx, g, kernel_in, kdtype, ctx->d_out, out_index ? static_cast<uint32_t *>(ctx->d_idx) : nullptr,
                ctx->d_counts, s, true);
   if (st != D2PC_OK) return st;
+  D2PC_HIP(ctx, mark(3));
   size_t n = g.roi_n;
   if (compact) {
     D2PC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -673,8 +690,15 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
     D2PC_HIP(ctx, hipMemcpyAsync(out_points, ctx->d_out, n * 16, hipMemcpyDeviceToHost, s));
     if (out_index) D2PC_HIP(ctx, hipMemcpyAsync(out_index, ctx->d_idx, n * 4, hipMemcpyDeviceToHost, s));
   }
+  D2PC_HIP(ctx, mark(4));
   D2PC_HIP(ctx, hipStreamSynchronize(s));
   drain.armed = false;
+  if (timing) {
+    float *t[4] = {&ctx->times.h2d_ms, &ctx->times.prep_ms, &ctx->times.kernel_ms, &ctx->times.d2h_ms};
+    for (int i = 0; i < 4; ++i) D2PC_HIP(ctx, hipEventElapsedTime(t[i], ctx->ev[i], ctx->ev[i + 1]));
+    D2PC_HIP(ctx, hipEventElapsedTime(&ctx->times.total_ms, ctx->ev[0], ctx->ev[4]));
+    ctx->have_times = true;
+  }
   *n_points = n;
   return D2PC_OK;
 }
@@ -939,6 +963,14 @@ int d2pc_pipeline_release(d2pc_ctx *ctx, int slot) {
   if (slot < 0 || slot >= ctx->pipe_depth || (ctx->slots[slot].state != 3 && ctx->slots[slot].state != 1))
     return fail(ctx, D2PC_ERR_INVALID_ARG, "slot %d is not collected (or acquired)", slot);
   ctx->slots[slot].state = 0;
+  return D2PC_OK;
+}
+
+int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times) {
+  if (!ctx || !times) return D2PC_ERR_INVALID_ARG;
+  if (!ctx->have_times)
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "no timed call yet: d2pc_set_tuning(ctx, \"stage_timing\", 1), then d2pc_process*");
+  *times = ctx->times;
   return D2PC_OK;
 }
 

@@ -80,6 +80,7 @@ class Disparity2PCloudT {
     if (st != D2PC_OK) throw std::runtime_error(std::string("d2pc_create: ") + d2pc_status_string(st));
     st = d2pc_set_q(ctx_, Q_);
     if (st != D2PC_OK) throw std::runtime_error(std::string("d2pc_set_q: ") + d2pc_status_string(st));
+    if (verbose_) d2pc_set_tuning(ctx_, "stage_timing", 1);  // the breadcrumbs below also say how long each stage took
   }
   ~Disparity2PCloudT() {
     if (ctx_) d2pc_destroy(ctx_);
@@ -124,6 +125,10 @@ class Disparity2PCloudT {
                                d2pc_last_error(ctx_));
     output.data.resize(n * 16);
     if (verbose_) printf("Cloud size: %zu\n", n);  // cpp:82
+    d2pc_stage_times tm;
+    if (verbose_ && d2pc_last_stage_times(ctx_, &tm) == D2PC_OK)
+      printf("upload %.3f ms, median %.3f ms, reproject %.3f ms, download %.3f ms\n", tm.h2d_ms, tm.prep_ms,
+             tm.kernel_ms, tm.d2h_ms);
 
     // cpp:79-85: width = N, height = 1, is_dense = false, field table
     d2pc_cloud_meta m;

@@ -327,11 +327,27 @@ int d2pc_rotate_cw_device(d2pc_ctx *ctx, const void *d_src, int cols, int rows, 
 int d2pc_crop_to_square(int cols, int rows, int offset_x, int offset_y, int member_offset_y,
                         int *x, int *y, int *n);
 
+/*
+ * Per-stage timing of the synchronous host entry points (d2pc_process,
+ * d2pc_process_mono8/16), the counterpart of the reference's printf
+ * breadcrumbs (cpp:47-91).  Off by default; d2pc_set_tuning(ctx,
+ * "stage_timing", 1) makes every call record HIP events on its stream.
+ * d2pc_last_stage_times returns the times of the last such call:
+ *   h2d_ms    upload of the frame
+ *   prep_ms   mono16 rescale + median (0 when neither runs)
+ *   kernel_ms reprojection (+ compaction)
+ *   d2h_ms    count readback + download of the points (and indices)
+ */
+typedef struct d2pc_stage_times {
+  float h2d_ms, prep_ms, kernel_ms, d2h_ms, total_ms;
+} d2pc_stage_times;
+int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
+
 /* Launch-shape tuning hook (no counterpart in the reference; results never
  * depend on it).  Keys: "pxt_parity", "pxt_compact" (ROI pixels per thread:
  * 4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by the tile count; 1..4096),
  * "onepass_blocks_per_cu", "force_general_q", "no_vec_rows", "fuse_rows" (rows per wave of
- * d2pc_fuse_device: 0 = choose, else even 2..1024). */
+ * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

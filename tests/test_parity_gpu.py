@@ -357,3 +357,20 @@ def test_disparity_image_style_calibration_and_threshold():
     assert_points_close(gp, wp, max_ulp=MAX_ULP)
     z = 520.0 * 0.11 / disp.reshape(-1)[gi].astype(np.float64)
     assert np.allclose(gp[:, 2], z, rtol=2e-7)
+
+
+def test_stage_timing_of_the_host_entry_points(q_default):
+    """per-stage HIP-event times of the synchronous host path."""
+    img = np.random.default_rng(1).integers(0, 256, size=(480, 752)).astype(np.uint8)
+    with d2pc.Context(q=q_default) as ctx:
+        ctx.process_mono8(img)
+        with pytest.raises(d2pc.D2pcError):
+            ctx.last_stage_times()                      # timing was off
+        ctx.set_tuning("stage_timing", 1)
+        ctx.process_mono8(img, median_ksize=11)
+        t = ctx.last_stage_times()
+        assert all(t[k] > 0 for k in ("h2d_ms", "prep_ms", "kernel_ms", "d2h_ms", "total_ms")), t
+        assert t["total_ms"] >= 0.99 * (t["h2d_ms"] + t["prep_ms"] + t["kernel_ms"] + t["d2h_ms"]), t
+        assert t["total_ms"] < 100.0
+        ctx.process(img.astype(np.float32))             # no median: prep stage is (nearly) empty
+        assert ctx.last_stage_times()["prep_ms"] < t["prep_ms"]
