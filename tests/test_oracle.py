@@ -302,3 +302,16 @@ def test_fusion_oracle_vs_exact_golden(golden_dir):
     fused, comb = oracle.fuse(planes)
     assert np.array_equal(fused, g["image__fused"])
     assert np.array_equal(comb, g["image__combined"])
+
+
+def test_oracle_under_asan_ubsan():
+    """sanitizers on the CPU code.  oracle/selftest.c calls every oracle entry point on small
+    and degenerate inputs in an -fsanitize=address,undefined build."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.run(["make", "-C", here, "sanitize"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
+               OMP_NUM_THREADS="2")
+    p = subprocess.run([os.path.join(here, "_selftest_asan")], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "oracle selftest ok" in p.stdout
