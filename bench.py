@@ -179,7 +179,21 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
-    rank, local_rank, world = multi_gpu.init_distributed()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when its first
+    # communicator comes up (the GPU boxes export NCCL_DEBUG=VERSION): fd 1 points at stderr until
+    # the first collective is through.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        rank, local_rank, world = multi_gpu.init_distributed()
+        multi_gpu.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     assert world == max(a.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {a.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
