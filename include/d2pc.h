@@ -173,7 +173,9 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale,
  * d_out_points + f*out_frame_stride_points*16 (and d_out_index +
  * f*out_frame_stride_points); d_counts[f] (uint32, nullable in PARITY)
  * receives the number of points of frame f.  All device pointers must belong
- * to the context's device; d_out_points must be 16-byte aligned.
+ * to the context's device; d_out_points must be 16-byte aligned -- 128-byte
+ * alignment (of the base and of out_frame_stride_points*16) keeps every wave
+ * store on whole 64-byte memory requests; a base 16 bytes off costs ~20 %.
  * Does not synchronise.  Call d2pc_reserve first if the call must be
  * capturable into a hipGraph (no allocation happens then).
  */

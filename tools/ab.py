@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--opbpc", type=int, default=4, help="single-pass kernel: persistent blocks per CU")
+    ap.add_argument("--oaligns", default="16", help="output frame stride rounded up to this many points (several: A/B)")
+    ap.add_argument("--ooffs", default="0", help="output base offset in points (several: A/B)")
     ap.add_argument("--w", type=int, default=3840)
     ap.add_argument("--h", type=int, default=2160)
     a = ap.parse_args()
@@ -50,34 +52,38 @@ def main():
     # ONE set of buffers for every candidate: kernel time depends on which
     # physical pages a buffer got (+-6 % between allocations of one process)
     W, H, F = a.w, a.h, a.frames
-    stride = (W * H + 15) // 16 * 16
-    points = torch.empty((F, stride, 4), dtype=torch.float32, device="cuda")
-    index = torch.empty((F, stride), dtype=torch.int32, device="cuda") if a.idx else None
+    oaligns = [int(x) for x in a.oaligns.split(",")]
+    ooffs = [int(x) for x in a.ooffs.split(",")]
+    max_stride = max((W * H + al - 1) // al * al for al in oaligns)
+    pool = torch.empty((F * max_stride + max(ooffs) + 16, 4), dtype=torch.float32, device="cuda")
+    index = torch.empty((F, max_stride), dtype=torch.int32, device="cuda") if a.idx else None
     counts = torch.zeros((F,), dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     class Cand:
-        def __init__(self, ctx):
+        def __init__(self, ctx, oalign, ooff):
             self.ctx = ctx
+            self.stride = (W * H + oalign - 1) // oalign * oalign
+            self.out_ptr = pool.data_ptr() + 16 * ooff
             ctx.reserve(W, H, F)
         def launch(self):
-            self.ctx.process_device(disp.data_ptr(), 0, 1.0, W, H, W * 4, W * H * 4, F, points.data_ptr(),
-                                    index.data_ptr() if index is not None else None, stride, counts.data_ptr(), stream)
+            self.ctx.process_device(disp.data_ptr(), 0, 1.0, W, H, W * 4, W * H * 4, F, self.out_ptr,
+                                    index.data_ptr() if index is not None else None, self.stride, counts.data_ptr(), stream)
 
     for lib in a.libs.split(","):
         L = load_variant(lib)
-        for mode, border, pxt, bpc, nv, algo in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(",")):
+        for mode, border, pxt, bpc, nv, algo, oal, oof in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(","), oaligns, ooffs):
             m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
             ctx = capi.Context(q=capi.make_q(), border=int(border), mode=m, compact_algo=int(algo))
             ctx.set_tuning("pxt_parity", int(pxt)); ctx.set_tuning("pxt_compact", int(pxt))
             ctx.set_tuning("blocks_per_cu", int(bpc)); ctx.set_tuning("no_vec_rows", int(nv))
             ctx.set_tuning("onepass_blocks_per_cu", a.opbpc)
-            b = Cand(ctx)
+            b = Cand(ctx, oal, oof)
             b.launch(); torch.cuda.synchronize()
             npts = int(counts.sum().item())
             roi_n = capi.roi_points(W, H, int(border))
             alg = 4 * F * roi_n + (20 if a.idx else 16) * npts
-            cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo}", b, alg, []))
+            cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo} oalign={oal} ooff={oof}", b, alg, []))
     for r in range(a.rounds):
         for label, b, alg, ts in cands:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
