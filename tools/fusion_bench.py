@@ -52,3 +52,13 @@ for (n, f) in ((465, 1), (465, 64), (1080, 32), (2160, 16), (2160, 64)):
             line += f"  rows={rows:2d} {us:7.1f} us {px/us/1e3:6.1f} Gpix/s {byts/us/1e3:5.0f} GB/s |"
         print(line, flush=True)
 ctx.close()
+
+# ---- rotateMat (d2pc_rotate_cw_device): 1 B read + 1 B written per pixel ----
+ctx = d2pc.Context(q=d2pc.make_q())
+for (rows, cols, f) in ((480, 752, 64), (2160, 3840, 16)):
+    src = torch.randint(0, 256, (f, rows, cols), dtype=torch.uint8, device="cuda")
+    dst = torch.empty((f, cols, rows), dtype=torch.uint8, device="cuda")
+    us = t(lambda: ctx.rotate_cw_device(src.data_ptr(), cols, rows, cols, cols * rows, f, dst.data_ptr(), rows, rows * cols, s))
+    px = f * rows * cols
+    print(f"rotate_cw {cols}x{rows} x{f:3d}: {us:8.1f} us  {px/us/1e3:8.1f} Gpix/s  {2*px/us/1e3:8.1f} GB/s algorithmic", flush=True)
+ctx.close()
