@@ -176,32 +176,41 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const ui
 // cv_bridge::toCvCopy(msg, "mono8") on a mono16 image (reference
 // src/disparity_to_point_cloud.cpp:50): image.convertTo(CV_8U, 255./65535.) =
 // saturate_cast<uchar>(cvRound(v * (float)(255./65535.))), product in float,
-// round-half-to-even.  Four pixels per thread.
+// round-half-to-even.  Eight pixels per thread (one 16-byte load, one 8-byte store when aligned).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_mono16_to_mono8(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                             const MedianArgs a) {
-  const uint32_t groups = (a.width + 3u) / 4u;  // per row
+  const uint32_t groups = (a.width + 7u) / 8u;  // eight pixels per thread and row
   const uint64_t total = uint64_t(groups) * a.height * a.n_frames;
   const float scale = float(255. / 65535.);
+  auto cvt = [&](uint32_t v) {
+    const float r = __builtin_rintf(float(v) * scale);  // default rounding mode: nearest-even
+    return uint32_t(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
+  };
   for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < total; i += uint64_t(gridDim.x) * kBlock) {
     const uint32_t gx = uint32_t(i % groups);
     const uint64_t r = i / groups;
     const uint32_t y = uint32_t(r % a.height), f = uint32_t(r / a.height);
-    const uint16_t *srow = reinterpret_cast<const uint16_t *>(src + uint64_t(f) * a.src_frame_stride + uint64_t(y) * a.src_row_stride);
+    const uint8_t *srow = src + uint64_t(f) * a.src_frame_stride + uint64_t(y) * a.src_row_stride;
     uint8_t *drow = dst + uint64_t(f) * a.dst_frame_stride + uint64_t(y) * a.dst_row_stride;
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k) {
-      const uint32_t x = gx * 4u + k;
-      if (x < a.width) {
-        const float v = __builtin_rintf(float(srow[x]) * scale);  // default rounding mode: nearest-even
-        drow[x] = uint8_t(v < 0.f ? 0.f : v > 255.f ? 255.f : v);
-      }
+    const uint32_t x = gx * 8u;
+    const uint8_t *sp = srow + 2u * x;
+    uint8_t *dp = drow + x;
+    if (x + 8u <= a.width && (reinterpret_cast<uintptr_t>(sp) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dp) & 7u) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(sp);  // 8 x uint16
+      uint2 o;
+      o.x = cvt(v.x & 0xffffu) | (cvt(v.x >> 16) << 8) | (cvt(v.y & 0xffffu) << 16) | (cvt(v.y >> 16) << 24);
+      o.y = cvt(v.z & 0xffffu) | (cvt(v.z >> 16) << 8) | (cvt(v.w & 0xffffu) << 16) | (cvt(v.w >> 16) << 24);
+      *reinterpret_cast<uint2 *>(dp) = o;
+    } else {
+      for (uint32_t k = 0; k < 8u && x + k < a.width; ++k)
+        dp[k] = uint8_t(cvt(reinterpret_cast<const uint16_t *>(sp)[k]));
     }
   }
 }
 
 hipError_t launch_mono16_to_mono8(const void *src, void *dst, const MedianArgs &a, hipStream_t stream) {
-  const uint64_t total = uint64_t((a.width + 3u) / 4u) * a.height * a.n_frames;
+  const uint64_t total = uint64_t((a.width + 7u) / 8u) * a.height * a.n_frames;
   if (total == 0) return hipErrorInvalidValue;
   const uint64_t want = (total + kBlock - 1) / kBlock;
   const uint32_t grid = uint32_t(want < 65536u ? want : 65536u);
