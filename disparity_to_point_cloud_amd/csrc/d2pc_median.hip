@@ -13,9 +13,11 @@
 //      finds its whole k-bit window inside one segment) and the segments of
 //      rows i and i+1 (the neighbouring lane's: one DPP move) are packed into
 //      one dword in LDS: pair[b][segment][i] = seg(i) | seg(i+1) << 16.
-//  2.  The median of the k*k window of pixel (y,x) is found MSB-first.  The
-//      candidate set is ceil(k/2) registers, each holding the k-bit masks of TWO
-//      window rows; per plane and register: ones = cand & pair word, n1 +=
+//  2.  The median of the k*k window of pixel (y,x) is found MSB-first (small
+//      windows: for two horizontally adjacent pixels per thread, which share
+//      every pair word).  The candidate set of a pixel is
+//      ceil(k/2) registers, each holding the k-bit masks of TWO window rows; per
+//      plane and register: ones = cand & pair word, n1 +=
 //      popcount, and after the rank test cand &= pair ^ flip -- three integer
 //      instructions (v_and, v_bcnt accumulate, v_bitop3) for two rows.
 //      k = 11: 8 planes x 6 registers x 3 = 144 ops per pixel (one row per
@@ -38,10 +40,15 @@ struct MedianShape {
   static constexpr int TH = 64;                    // tile height
   static constexpr int IN_ROWS = TH + 2 * R;
   static constexpr int NREG = (KS + 1) / 2;        // row pairs per window
-  static constexpr int THREADS = (TW * TH) % 256 == 0 ? 256 : 192;
+  // Small windows: a thread selects for TWO horizontally adjacent pixels (they share every pair word:
+  // 3x3 +6 %, same device); at 9x9 and 11x11 the second pixel's registers cost a wave of occupancy (-3 %).
+  static constexpr int NPX = KS <= 5 ? 2 : 1;
+  static constexpr int ITEMS = TW / NPX * TH;
+  static constexpr int THREADS = ITEMS % 256 == 0 ? 256 : ITEMS % 192 == 0 ? 192 : ITEMS % 320 == 0 ? 320 : 128;
+  static_assert(SEG_PX % 2 == 0 && TW % 2 == 0, "a pixel pair never straddles two segments");
   static_assert((NSEG - 1) * SEG_PX + 16 <= 32, "segments must lie inside the plane word");
   static_assert(TW + KS - 1 <= 32, "the tile's windows must lie inside the plane word");
-  static_assert((TW * TH) % THREADS == 0, "whole passes over the tile");
+  static_assert(ITEMS % THREADS == 0, "whole passes over the tile");
   static_assert(IN_ROWS <= 2 * 63 && THREADS >= 128, "two waves of 63 row pairs cover the input rows");
 };
 
@@ -129,46 +136,59 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const ui
   }
   __syncthreads();
 
-  // ---- 2. radix select per output pixel ---------------------------------------------
+  // ---- 2. radix select, NPX horizontally adjacent pixels per thread ------------------------------
   constexpr uint32_t kField = (1u << KS) - 1u;
+  constexpr int NPX = S::NPX;
 #pragma unroll 1
-  for (int it = 0; it < S::TW * S::TH / S::THREADS; ++it) {
+  for (int it = 0; it < S::ITEMS / S::THREADS; ++it) {
     const uint32_t p = tid + uint32_t(it) * uint32_t(S::THREADS);
-    const uint32_t y = p / uint32_t(S::TW), x = p - y * uint32_t(S::TW);
+    const uint32_t y = p / uint32_t(S::TW / NPX), x = uint32_t(NPX) * (p - y * uint32_t(S::TW / NPX));
     const uint32_t sg = x / uint32_t(S::SEG_PX), xs = x - sg * uint32_t(S::SEG_PX);
-    const uint32_t one_row = kField << xs;  // <= 16 bits by construction
-    uint32_t cand[S::NREG];
+    uint32_t cand[NPX][S::NREG];
 #pragma unroll
-    for (int j = 0; j < S::NREG; ++j) cand[j] = one_row | (one_row << 16);
-    if (KS & 1) cand[S::NREG - 1] = one_row;  // the last register holds one window row only
+    for (int q = 0; q < NPX; ++q) {
+      const uint32_t one_row = kField << (xs + uint32_t(q));  // <= 16 bits by construction
+#pragma unroll
+      for (int j = 0; j < S::NREG; ++j) cand[q][j] = one_row | (one_row << 16);
+      if (KS & 1) cand[q][S::NREG - 1] = one_row;  // the last register holds one window row only
+    }
     // With c candidates left and the median the (a+1)-th smallest of them, only d = c - a - 1 has to
     // be carried: the median's bit is 1  <=>  zeros <= a  <=>  z = d - ones < 0; then d stays (c and a
     // shrink by the same number of zeros), otherwise d = z.  Five integer ops per plane.
-    int32_t d = KS * KS - (KS * KS / 2 + 1);
-    int32_t acc = 0;  // minus the median, built MSB first
+    int32_t d[NPX], acc[NPX];  // acc: minus the median, built MSB first
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) d[q] = KS * KS - (KS * KS / 2 + 1), acc[q] = 0;
 #pragma unroll
     for (int pl = 7; pl >= 0; --pl) {
       uint32_t word[S::NREG];
-      uint32_t n1 = 0;
 #pragma unroll
-      for (int j = 0; j < S::NREG; ++j) {
-        word[j] = s_pair[pl][sg][y + 2u * uint32_t(j)];
-        n1 += uint32_t(__popc(cand[j] & word[j]));
-      }
-      const int32_t z = d - int32_t(n1);
-      const int32_t is1 = z >> 31;  // all ones when the median's bit is 1
-      // keep the candidates whose bit equals the median's: cand & ~(word ^ is1) is ONE v_bitop3 per
-      // register (as an intrinsic: written with operators, LLVM folds it into the next plane's AND
-      // and spends a fourth instruction on the shared term)
-      if (pl > 0) {
+      for (int j = 0; j < S::NREG; ++j) word[j] = s_pair[pl][sg][y + 2u * uint32_t(j)];
 #pragma unroll
-        for (int j = 0; j < S::NREG; ++j) cand[j] = __builtin_amdgcn_bitop3_b32(word[j], cand[j], uint32_t(is1), 0x84);
+      for (int q = 0; q < NPX; ++q) {
+        uint32_t n1 = 0;
+#pragma unroll
+        for (int j = 0; j < S::NREG; ++j) n1 += uint32_t(__popc(cand[q][j] & word[j]));
+        const int32_t z = d[q] - int32_t(n1);
+        const int32_t is1 = z >> 31;  // all ones when the median's bit is 1
+        // keep the candidates whose bit equals the median's: cand & ~(word ^ is1) is ONE v_bitop3 per
+        // register (as an intrinsic: written with operators, LLVM folds it into the next plane's AND
+        // and spends a fourth instruction on the shared term)
+        if (pl > 0) {
+#pragma unroll
+          for (int j = 0; j < S::NREG; ++j)
+            cand[q][j] = __builtin_amdgcn_bitop3_b32(word[j], cand[q][j], uint32_t(is1), 0x84);
+        }
+        d[q] = z + (int32_t(n1) & is1);
+        acc[q] = (acc[q] << 1) + is1;
       }
-      d = z + (int32_t(n1) & is1);
-      acc = (acc << 1) + is1;
     }
     const uint32_t oy = uint32_t(y0) + y, ox = uint32_t(c0) + x;
-    if (oy < a.height && ox < a.width) fdst[uint64_t(oy) * a.dst_row_stride + ox] = uint8_t(-acc);
+    if (oy < a.height) {
+      uint8_t *o = fdst + uint64_t(oy) * a.dst_row_stride + ox;
+#pragma unroll
+      for (int q = 0; q < NPX; ++q)
+        if (ox + uint32_t(q) < a.width) o[q] = uint8_t(-acc[q]);
+    }
   }
 }
 

@@ -6,6 +6,10 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import disparity_to_point_cloud_amd as d2pc
+from disparity_to_point_cloud_amd import capi
+if len(sys.argv) > 1:  # tuning build: make -C disparity_to_point_cloud_amd/csrc variant NAME=x
+    capi._LIB_NAME = f"libd2pc_{sys.argv[1]}.so"
+    print("library:", capi._LIB_NAME)
 from disparity_to_point_cloud_amd.torch_api import DeviceBatch
 
 def t(fn, iters=10, rounds=5):
