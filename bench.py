@@ -177,6 +177,9 @@ def main():
     ap.add_argument("--mode", choices=["parity", "compact"], default="parity")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the PCIe-inclusive side measurement (its single-frame and host-memory launches would "
+                         "mix into the per-kernel averages of a rocprofv3 --stats run)")
     a = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when its first
@@ -315,7 +318,8 @@ def main():
             "kernel_ms_avg": round(kms, 4), "what": "fused cpp:61 decode: 1 B read + 16 B written per pixel"}
         del b3
         c3.close()
-        variants["host_path_pcie_inclusive_1x4K_parity"] = host_path_rates(q, a.border)
+        if not a.no_host_path:
+            variants["host_path_pcie_inclusive_1x4K_parity"] = host_path_rates(q, a.border)
         out["variants_1gpu"] = variants
     if rank == 0 and world == 1 and not a.no_cpu:  # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(q, a.border)
