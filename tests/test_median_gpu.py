@@ -126,3 +126,38 @@ def test_process_mono16_is_the_whole_callback(mode, k):
                 assert_points_close(gp, wp, max_ulp=1)
             with pytest.raises(d2pc.D2pcError):
                 ctx.process_mono16(img, median_ksize=4)
+
+
+def test_callback_body_is_graph_capturable():
+    """mono16 rescale -> median 11 -> reproject, device-resident, captured into ONE hipGraph and replayed."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    q = d2pc.make_q()
+    rng = np.random.default_rng(8)
+    imgs = rng.integers(0, 65536, size=(3, 240, 376)).astype(np.uint16)
+    n, h, w = imgs.shape
+    with d2pc.Context(q=q) as ctx:
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8)
+        src = torch.from_numpy(imgs.view(np.int16)).cuda()
+        m8 = torch.empty((n, h, w), dtype=torch.uint8, device="cuda")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            def body():
+                s = torch.cuda.current_stream().cuda_stream
+                ctx.mono16_to_mono8_device(src.data_ptr(), w, h, 2 * w, 2 * w * h, n, m8.data_ptr(), w, w * h, s)
+                ctx.median_device(m8.data_ptr(), w, h, w, w * h, n, b.disp.data_ptr(), w, w * h, 11, s)
+                b.launch(scale=0.125)
+            body()                      # warm-up outside the capture
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                body()
+            b.points.zero_()
+            src.copy_(torch.from_numpy(np.roll(imgs, 1, axis=0).view(np.int16)).cuda())   # new input, same graph
+            g.replay()
+        torch.cuda.synchronize()
+        res = b.results()
+    for f in range(n):
+        want = oracle.reproject(oracle.median_u8(oracle.mono16_to_mono8(np.roll(imgs, 1, axis=0)[f]), 11), q, border=40,
+                                scale=0.125)
+        assert_points_close(res[f][0], want, max_ulp=1, what=f"graph replay, frame {f}")
