@@ -28,7 +28,7 @@ def _run(world, where):
         assert f"rank {r}/{world} ok" in p.stdout
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])  # 8 = the node the scaling bench runs on
 def test_calibration_broadcast_and_sharding_gloo(world):
     _run(world, "cpu")
 
