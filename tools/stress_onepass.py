@@ -12,11 +12,17 @@ from disparity_to_point_cloud_amd.torch_api import DeviceBatch
 
 launches = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+contend = len(sys.argv) > 3 and sys.argv[3] == "contend"   # keep the GPU busy with 11x11 medians on another stream
 rng = np.random.default_rng(seed)
 g = torch.Generator(device="cuda").manual_seed(seed)
 q = d2pc.make_q()
 t0 = time.time()
 done = 0
+if contend:
+    side = torch.cuda.Stream()
+    cctx = d2pc.Context(q=q)
+    craw = torch.randint(0, 256, (8, 2160, 3840), dtype=torch.uint8, device="cuda")
+    cout = torch.empty_like(craw)
 while done < launches:
     n = int(rng.choice([1, 2, 4, 5, 8, 16, 24, 40]))
     w, h = (int(rng.integers(64, 2000)), int(rng.integers(64, 1200)))
@@ -42,6 +48,10 @@ while done < launches:
             if idx: b.index.fill_(-7)
             b.disp.copy_(disp)
             reps = 1 if algo == 1 else int(rng.integers(1, 4))
+            if contend and algo == 2:
+                for _ in range(3):
+                    cctx.median_device(craw.data_ptr(), 3840, 2160, 3840, 3840 * 2160, 8, cout.data_ptr(), 3840, 3840 * 2160,
+                                       11, side.cuda_stream)
             for _ in range(reps): b.launch()
             torch.cuda.synchronize()
             ctx.check_async_error()
