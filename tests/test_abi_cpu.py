@@ -161,3 +161,18 @@ def test_crop_to_square_matches_oracle_without_a_gpu():
     d = d2pc.fuse_desc_init()
     assert (d.struct_size, d.rule, d.n_frames) == (ctypes.sizeof(d2pc.FuseDesc), d2pc.FUSE_GRAD_FILTER, 1)
     assert (d.crop_left, d.crop_right, d.crop_top, d.crop_bottom) == (0, 40, 30, 10)   # cpp:130
+
+
+def test_public_header_is_plain_c99_and_cxx11(tmp_path):
+    """The boundary is a C ABI: include/d2pc.h must compile as strict C99 (and C++11) with no warnings."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "d2pc.h"\nint main(void) { d2pc_config c; d2pc_fuse_desc f; d2pc_frame_desc d; '
+                   'd2pc_stage_times t; d2pc_cloud_meta m; (void)c; (void)f; (void)d; (void)t; (void)m; '
+                   'return D2PC_ABI_VERSION == 1 ? 0 : 1; }\n')
+    inc = os.path.join(root, "include")
+    for cmd in (["gcc", "-std=c99"], ["g++", "-std=c++11", "-x", "c++"]):
+        p = subprocess.run(cmd + ["-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o",
+                                  str(tmp_path / "hdr.o")], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
