@@ -10,6 +10,13 @@ over a ring of 16 distinct synthetic 4K frames already resident in HBM
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N
+ranks itself: the parent -- which imports neither torch nor the HIP library, so
+it never touches a GPU -- runs `python -m torch.distributed.run` as a CHILD
+process (reference src/disparity_to_point_cloud_node.cpp:46-52: one process per
+node, here one per GPU), relays rank 0's JSON line and exits with the child's
+code.  A rank whose WORLD_SIZE differs from --gpus fails.
+
 Prints ONE JSON line (rank 0) with `roofline` (algorithmic bytes / measured
 kernel time vs 8 TB/s HBM peak) and `cpu_baseline` (the oracle's single-thread
 restatement of the reference loop timed on this host, bounded sample).
@@ -17,14 +24,79 @@ restatement of the reference loop timed on this host, bounded sample).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+# --------------------------------------------------------------------------
+# launcher (stdlib only: runs in a parent that must never initialise the GPU)
+# --------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n_ranks, script, script_args, timeout=None, env=None):
+    """Start `script` as n_ranks torch.distributed ranks on this node (a child
+    process, never an exec) and return (returncode, stdout, stderr-relayed).
+    The child's stderr goes straight to ours; its stdout is captured so that
+    only the JSON line reaches our stdout."""
+    e = dict(os.environ if env is None else env)
+    e.setdefault("MASTER_ADDR", "127.0.0.1")
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    e.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script] + list(script_args)
+    p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, text=True, timeout=timeout)
+    return p.returncode, p.stdout
+
+
+def relay_json_line(stdout_text, out=sys.stdout, err=sys.stderr):
+    """Print the ranks' ONE JSON result line to `out`, everything else they wrote
+    to stdout (library banners) to `err`.  Returns the parsed line or None."""
+    found = None
+    for line in stdout_text.splitlines():
+        s = line.strip()
+        rec = None
+        if s.startswith("{") and s.endswith("}"):
+            try:
+                rec = json.loads(s)
+            except ValueError:
+                rec = None
+        if isinstance(rec, dict) and "metric" in rec and found is None:
+            found = rec
+            print(s, file=out, flush=True)
+        elif s:
+            print(line, file=err, flush=True)
+    return found
+
+
+def launch_if_needed(argv):
+    """--gpus N > 1 outside a torchrun environment: become the launcher."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    known, _ = ap.parse_known_args(argv)
+    if known.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    rc, text = spawn_ranks(known.gpus, os.path.abspath(__file__), argv)
+    rec = relay_json_line(text)
+    if rc == 0 and (rec is None or rec.get("n_gpus") != known.gpus):
+        print(f"bench.py: the {known.gpus} ranks exited 0 without a result line for n_gpus={known.gpus}", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    launch_if_needed(sys.argv[1:])  # before torch / libd2pc.so are imported
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 import disparity_to_point_cloud_amd as d2pc  # noqa: E402
 from disparity_to_point_cloud_amd import multi_gpu  # noqa: E402
@@ -180,7 +252,15 @@ def main():
     ap.add_argument("--no-host-path", action="store_true",
                     help="skip the PCIe-inclusive side measurement (its single-frame and host-memory launches would "
                          "mix into the per-kernel averages of a rocprofv3 --stats run)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                    help="torch.distributed backend for N > 1 (default: nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL ONLY: all ranks use cuda:0 (needs --backend gloo; RCCL refuses two ranks on one "
+                         "device).  Exercises the N-rank launch/barrier/report path on a 1-GPU box; the line is "
+                         "marked rehearsal_shared_gpu and is not a scaling measurement")
     a = ap.parse_args()
+    if a.share_gpu and a.backend != "gloo":
+        raise SystemExit("--share-gpu needs --backend gloo")
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when its first
     # communicator comes up (the GPU boxes export NCCL_DEBUG=VERSION): fd 1 points at stderr until
@@ -189,7 +269,7 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        rank, local_rank, world = multi_gpu.init_distributed()
+        rank, local_rank, world = multi_gpu.init_distributed(backend=a.backend, share_gpu=a.share_gpu)
         multi_gpu.barrier()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
@@ -197,9 +277,16 @@ def main():
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
-    assert world == max(a.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {a.gpus}"
+    if world != max(a.gpus, 1):
+        raise SystemExit(f"bench.py: WORLD_SIZE {world} != --gpus {a.gpus} (start it as `python bench.py --gpus N` or "
+                         f"under torch.distributed.run with --nproc-per-node N)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if a.share_gpu:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but this node exposes "
+                         f"{torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     mode = d2pc.MODE_PARITY if a.mode == "parity" else d2pc.MODE_COMPACT
@@ -220,6 +307,7 @@ def main():
     wall, kernel_ms = timed_steps(batch, a.steps, a.warmup, multi_gpu.barrier)
     wall = multi_gpu.allreduce_max(wall)
     kernel_ms_max = multi_gpu.allreduce_max(kernel_ms)
+    per_rank_kernel_ms = multi_gpu.allgather_floats(kernel_ms)
     if mode == d2pc.MODE_COMPACT:
         ctx.check_async_error()
 
@@ -245,6 +333,7 @@ def main():
                         f"border {a.border}, mode {a.mode}, one stream per GPU, Q broadcast from rank 0",
             "frames_per_step": a.frames, "width": W4K, "height": H4K, "border": a.border, "mode": a.mode,
             "points_per_step": n_points,
+            "collective_backend": multi_gpu.backend_name(),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -252,9 +341,12 @@ def main():
             "kernel": "k_reproject_pack" if mode == d2pc.MODE_PARITY else "k_compact_onepass",
             "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": round(kernel_ms, 4),
             "kernel_ms_avg_max_over_ranks": round(kernel_ms_max, 4),
+            "kernel_ms_avg_per_rank": [round(x, 4) for x in per_rank_kernel_ms],
             "read_component_GBs": round(4 * a.frames * batch.roi_n / (kernel_ms * 1e-3) / 1e9, 1),
         },
     }
+    if a.share_gpu:
+        out["config"]["rehearsal_shared_gpu"] = True
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(prof):
         try:

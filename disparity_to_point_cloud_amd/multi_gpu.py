@@ -19,16 +19,21 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, share_gpu=False):
     """Initialise torch.distributed from the torchrun environment (no-op for a
-    single process).  Returns (rank, local_rank, world_size)."""
+    single process).  Returns (rank, local_rank, world_size).  The backend is
+    taken from the argument, else D2PC_DIST_BACKEND, else "nccl" (= RCCL) when
+    the node exposes GPUs -- decided by COUNTING devices, which does not
+    initialise the GPU.  share_gpu: every rank uses device 0 (gloo rehearsal)."""
     rank, local_rank, world = env_world()
+    if share_gpu:
+        local_rank = 0
     # D2PC_FORCE_DIST=1 initialises the group even for one rank (exercises RCCL on a 1-GPU box)
     if (world > 1 or os.environ.get("D2PC_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("D2PC_DIST_BACKEND") or ("nccl" if torch.cuda.device_count() > 0 else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend=backend, rank=rank, world_size=world,
@@ -83,6 +88,20 @@ def allreduce_max(x: float) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=_comm_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def allgather_floats(x: float):
+    """Every rank's value of x, in rank order."""
+    if not dist.is_initialized():
+        return [float(x)]
+    t = torch.tensor([x], dtype=torch.float64, device=_comm_device())
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_initialized() else None
 
 
 def allreduce_sum_counters(counters) -> np.ndarray:

@@ -15,8 +15,42 @@ import disparity_to_point_cloud_amd as d2pc  # noqa: E402
 from disparity_to_point_cloud_amd import multi_gpu  # noqa: E402
 
 
+def rccl_one_rank():
+    """backend "nccl" (= RCCL) with one rank: the calibration blob goes through an RCCL broadcast on the
+    device and must come back bit for bit; the reporting collectives run on RCCL too."""
+    import oracle
+    from helpers import assert_points_close, synth_disparity
+
+    rank, local_rank, world = multi_gpu.init_distributed()  # default decision: GPUs present => nccl
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+    q0 = d2pc.make_q(fx=700.0, fy=690.5, cx=333.25, cy=250.0, baseline=0.043, nx=640, ny=480)
+    src = d2pc.Context(device_id=local_rank, q=q0, border=24, mode=d2pc.MODE_COMPACT)
+    blob0 = src.export_calibration()
+    blob = multi_gpu.broadcast_blob(blob0, src=0)           # host -> device -> ncclBroadcast -> host
+    assert blob == blob0 and len(blob) == d2pc.CALIB_BLOB_BYTES
+    q, border, mode = d2pc.calib_unpack(blob)
+    assert q.tobytes() == q0.tobytes() and np.signbit(q[15]) and (border, mode) == (24, d2pc.MODE_COMPACT)
+    assert multi_gpu.broadcast_calibration(src, src=0) == blob0
+    assert multi_gpu.allreduce_max(2.5) == 2.5 and multi_gpu.allgather_floats(1.25) == [1.25]
+    assert list(multi_gpu.allreduce_sum_counters([3, 4])) == [3, 4]
+    dst = d2pc.Context(device_id=local_rank)
+    dst.import_calibration(blob)
+    disp = synth_disparity(5, 0, 640, 480, "holes")
+    gp, gi = dst.process(disp, want_index=True)
+    wp, wi = oracle.reproject_compact(disp, q0, border=24)
+    assert np.array_equal(gi, wi)
+    assert_points_close(gp, wp, max_ulp=1, rel=1e-5, what="rccl-broadcast calibration")
+    src.close()
+    dst.close()
+    multi_gpu.barrier()
+    dist.destroy_process_group()
+    print("rank 0/1 ok backend=nccl")
+
+
 def main():
     where = sys.argv[1]
+    if where == "rccl1":
+        return rccl_one_rank()
     rank, local_rank, world = multi_gpu.init_distributed(backend="gloo")
     assert dist.is_initialized() and world == int(os.environ["WORLD_SIZE"]) and world >= 2
 
