@@ -431,10 +431,15 @@ class Context:
         """Oldest submitted frame -> (points, index or None, tag, slot).  With
         copy=False the arrays are VIEWS of the pinned buffers, valid until
         pipeline_release(slot)."""
-        slot, pts, idx = ctypes.c_int(), ctypes.c_void_p(), ctypes.c_void_p()
+        slot, pts, idx = ctypes.c_int(-1), ctypes.c_void_p(), ctypes.c_void_p()
         n, tag = ctypes.c_size_t(), ctypes.c_uint64()
-        self._check(self._L.d2pc_pipeline_collect(self._h, ctypes.byref(slot), ctypes.byref(pts), ctypes.byref(idx),
-                                                  ctypes.byref(n), ctypes.byref(tag)))
+        st = self._L.d2pc_pipeline_collect(self._h, ctypes.byref(slot), ctypes.byref(pts), ctypes.byref(idx),
+                                           ctypes.byref(n), ctypes.byref(tag))
+        if st:
+            msg = self._L.d2pc_last_error(self._h).decode()
+            if slot.value >= 0:  # the frame is lost but its slot was handed back: free it before raising
+                self._L.d2pc_pipeline_release(self._h, slot.value)
+            raise D2pcError(st, msg)
         if n.value:
             p = np.ctypeslib.as_array(ctypes.cast(pts, ctypes.POINTER(ctypes.c_float)), shape=(n.value, 4))
             i = (np.ctypeslib.as_array(ctypes.cast(idx, ctypes.POINTER(ctypes.c_uint32)), shape=(n.value,))

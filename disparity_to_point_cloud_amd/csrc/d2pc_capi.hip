@@ -17,6 +17,21 @@
 
 using namespace d2pc;
 
+// One compaction-state buffer.  A COMPACT launch owns its buffer from the zeroing memset to its last
+// store, so launches that may overlap (different streams, a captured graph being replayed) never share one.
+struct StateBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipStream_t stream = nullptr;  // stream of the last launch that used it (valid when `bound`)
+  bool bound = false;
+  hipEvent_t done = nullptr;     // recorded behind that launch (not while capturing)
+  bool pending = false;          // `done` was recorded and has not been seen complete yet
+  int algo = 0;                  // algorithm of that launch: 2 = single pass (its header holds the timeout flag)
+  bool captured = false;         // a stream capture baked the pointer into a graph: never freed, moved or shared
+  unsigned long long capture_id = 0;
+};
+constexpr int kMaxStateBufs = 8;
+
 // One frame in flight on the pipelined host path (d2pc_pipeline_*).
 struct PipeSlot {
   hipStream_t stream = nullptr;
@@ -29,7 +44,7 @@ struct PipeSlot {
   void *d_cvt = nullptr;     size_t d_cvt_cap = 0;   // MONO16 frames rescaled to 8 bits
   void *d_out = nullptr;     size_t d_out_cap = 0;
   void *d_idx = nullptr;     size_t d_idx_cap = 0;
-  void *d_state = nullptr;   size_t d_state_cap = 0;
+  StateBuf st;                                       // the slot's own compaction state
   uint32_t *d_count = nullptr;
   d2pc_frame_desc desc{};
   size_t roi_n = 0, idx_off = 0;
@@ -51,7 +66,7 @@ struct d2pc_ctx {
   int pxt_parity = 8, pxt_compact = 8;
   int blocks_per_cu = 128;
   int onepass_blocks_per_cu = 4;
-  int last_compact_algo = 0;  // what the last COMPACT launch used
+  int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
   int no_vec_rows = 0;
   int stage_timing = 0;          // record per-stage HIP events in the synchronous host entry points
@@ -60,7 +75,8 @@ struct d2pc_ctx {
   bool have_times = false;
   int fuse_rows = 0;             // d2pc_fuse_device rows per wave: 0 = choose, else 2..1024
   // device scratch
-  void *d_state = nullptr;   size_t state_cap = 0;
+  StateBuf states[kMaxStateBufs];  // compaction state, one per stream with COMPACT work in flight
+  size_t state_reserve = 0;        // d2pc_reserve: every buffer is at least this large
   void *d_in = nullptr;      size_t in_cap = 0;
   void *d_out = nullptr;     size_t out_cap = 0;
   void *d_idx = nullptr;     size_t idx_cap = 0;
@@ -176,16 +192,108 @@ int make_geom(d2pc_ctx *ctx, int dtype, float scale, int width, int height, size
   g->out_frame_stride = out_frame_stride;
   g->scale = scale;
   g->min_disparity = ctx->cfg.min_disparity;
+  g->spin_ticks = uint32_t(ctx->spin_timeout_ms) * kSpinTicksPerMs;
+  return D2PC_OK;
+}
+
+// Is `s` capturing, and if so which capture?
+bool capture_info(hipStream_t s, unsigned long long *id) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long cid = 0;
+  if (hipStreamGetCaptureInfo(s, &st, &cid) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  if (id) *id = cid;
+  return st != hipStreamCaptureStatusNone;
+}
+
+bool state_idle(StateBuf &b) {
+  if (!b.pending) return true;
+  if (hipEventQuery(b.done) == hipSuccess) {
+    b.pending = false;
+    return true;
+  }
+  (void)hipGetLastError();  // hipErrorNotReady is not an error here
+  return false;
+}
+
+int state_alloc(d2pc_ctx *ctx, StateBuf &b, size_t need) {
+  if (need < ctx->state_reserve) need = ctx->state_reserve;
+  if (!b.done) D2PC_HIP(ctx, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+  if (b.p && b.cap >= need) return D2PC_OK;
+  if (b.p) {
+    if (b.pending) D2PC_HIP(ctx, hipEventSynchronize(b.done));  // its last launch still reads and writes it
+    b.pending = false;
+  }
+  return grow(ctx, &b.p, &b.cap, need);
+}
+
+// The compaction state for a launch of `need` bytes on `stream`.
+//  * launches on ONE stream are ordered, so a stream keeps reusing its buffer;
+//  * a launch on another stream takes a buffer whose last launch has completed, or a new one -- two
+//    launches that may overlap never share tickets / partial counts / granules;
+//  * during stream capture nothing can be allocated, and the pointer is baked into the graph: the buffer
+//    must exist already (d2pc_reserve) and from then on belongs to that capture alone -- it is never
+//    freed, grown or handed to another launch, so replaying the graph stays valid whatever is called later.
+int acquire_state(d2pc_ctx *ctx, hipStream_t stream, size_t need, StateBuf *fixed, StateBuf **out) {
+  unsigned long long cid = 0;
+  const bool capturing = capture_info(stream, &cid);
+  if (fixed) {  // pipeline slot: the slot's stream orders everything that touches its buffer
+    if (capturing) return fail(ctx, D2PC_ERR_INVALID_ARG, "pipeline streams cannot be captured");
+    int st = state_alloc(ctx, *fixed, need);
+    if (st != D2PC_OK) return st;
+    fixed->stream = stream;
+    fixed->bound = true;
+    *out = fixed;
+    return D2PC_OK;
+  }
+  StateBuf *pick = nullptr;
+  if (capturing) {
+    for (StateBuf &b : ctx->states)  // an earlier launch of the same capture: ordered inside the graph
+      if (b.p && b.captured && b.capture_id == cid && b.cap >= need) pick = &b;
+    if (!pick)
+      for (StateBuf &b : ctx->states)
+        if (b.p && !b.captured && b.cap >= need && state_idle(b) && (!pick || b.cap < pick->cap)) pick = &b;
+    if (!pick)
+      return fail(ctx, D2PC_ERR_OUT_OF_MEMORY,
+                  "no free compaction state of %zu bytes for a captured launch: call d2pc_reserve(width, height, "
+                  "n_frames) for the largest batch before every capture", need);
+    pick->captured = true;
+    pick->capture_id = cid;
+  } else {
+    for (StateBuf &b : ctx->states)
+      if (b.p && !b.captured && b.bound && b.stream == stream) pick = &b;
+    if (!pick)  // the smallest idle buffer that fits, else any idle one (it is grown), else an empty slot
+      for (StateBuf &b : ctx->states)
+        if (b.p && !b.captured && state_idle(b) && b.cap >= need && (!pick || b.cap < pick->cap)) pick = &b;
+    if (!pick)
+      for (StateBuf &b : ctx->states)
+        if (b.p && !b.captured && state_idle(b)) pick = &b;
+    if (!pick)
+      for (StateBuf &b : ctx->states)
+        if (!b.p && !pick) pick = &b;
+    if (!pick) {  // every slot is busy on some other stream: wait for one that is not a graph's
+      for (StateBuf &b : ctx->states)
+        if (!b.captured && !pick) pick = &b;
+      if (!pick)
+        return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "all %d compaction state buffers belong to captured graphs", kMaxStateBufs);
+    }
+    int st = state_alloc(ctx, *pick, need);  // waits for the buffer's last launch before it frees anything
+    if (st != D2PC_OK) return st;
+    if (pick->pending && !(pick->bound && pick->stream == stream)) {
+      // taken over from another stream while busy (only when all slots were busy): order behind it
+      D2PC_HIP(ctx, hipStreamWaitEvent(stream, pick->done, 0));
+    }
+  }
+  pick->stream = stream;
+  pick->bound = true;
+  *out = pick;
   return D2PC_OK;
 }
 
 int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d_out, uint32_t *d_idx,
-            uint32_t *d_counts, hipStream_t stream, bool allow_alloc, void **state_buf = nullptr,
-            size_t *state_cap = nullptr) {
-  if (!state_buf) {
-    state_buf = &ctx->d_state;
-    state_cap = &ctx->state_cap;
-  }
+            uint32_t *d_counts, hipStream_t stream, StateBuf *fixed_state = nullptr, int force_algo = 0) {
   LaunchArgs a;
   a.disp = d_disp;
   a.out_points = d_out;
@@ -229,8 +337,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   // 256 x 752x480: 278 vs 290; but 8 x 1080p: 68 vs 61) -- and needs a few frames in flight, because a
   // frame's ticket word serialises at ~18 ns per tile (one 4K frame: 72 vs 35 us)
   const bool big_batch = g.n_frames >= 4 && g.total_tiles >= 24576;
-  a.compact_algo = ctx->cfg.compact_algo ? ctx->cfg.compact_algo : (big_batch ? 2 : 1);
-  ctx->last_compact_algo = a.compact_algo;
+  a.compact_algo = force_algo ? force_algo : ctx->cfg.compact_algo ? ctx->cfg.compact_algo : (big_batch ? 2 : 1);
   if (a.compact_algo == 2) {
     // the single-pass kernel is software-pipelined over a block's tiles: it
     // wants few, long-lived blocks (about what is resident), not many short ones
@@ -238,13 +345,16 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     a.grid = g.total_tiles < persistent ? g.total_tiles : persistent;
   }
   a.state_bytes = compact_state_bytes(g);
-  if (a.state_bytes > *state_cap) {
-    if (!allow_alloc) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "compaction state not reserved (call d2pc_reserve)");
-    int st = grow(ctx, state_buf, state_cap, a.state_bytes);
-    if (st != D2PC_OK) return st;
-  }
-  a.state = *state_buf;
+  StateBuf *sb = nullptr;
+  int st = acquire_state(ctx, stream, a.state_bytes, fixed_state, &sb);
+  if (st != D2PC_OK) return st;
+  a.state = sb->p;
+  sb->algo = a.compact_algo;
   D2PC_HIP(ctx, launch_compact(a));
+  if (!sb->captured) {  // an event record inside a capture would become a graph node; a captured buffer is never shared
+    D2PC_HIP(ctx, hipEventRecord(sb->done, stream));
+    sb->pending = true;
+  }
   return D2PC_OK;
 }
 
@@ -277,12 +387,6 @@ struct SyncOnExit {
     if (armed) (void)hipStreamSynchronize(s);
   }
 };
-
-bool stream_is_capturing(hipStream_t s) {
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &st) != hipSuccess) return false;
-  return st != hipStreamCaptureStatusNone;
-}
 
 }  // namespace
 
@@ -389,7 +493,10 @@ int d2pc_destroy(d2pc_ctx *ctx) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->d_state) (void)hipFree(ctx->d_state);
+  for (StateBuf &b : ctx->states) {
+    if (b.p) (void)hipFree(b.p);
+    if (b.done) (void)hipEventDestroy(b.done);
+  }
   if (ctx->d_in) (void)hipFree(ctx->d_in);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_idx) (void)hipFree(ctx->d_idx);
@@ -407,7 +514,8 @@ int d2pc_destroy(d2pc_ctx *ctx) {
     if (sl.d_cvt) (void)hipFree(sl.d_cvt);
     if (sl.d_out) (void)hipFree(sl.d_out);
     if (sl.d_idx) (void)hipFree(sl.d_idx);
-    if (sl.d_state) (void)hipFree(sl.d_state);
+    if (sl.st.p) (void)hipFree(sl.st.p);
+    if (sl.st.done) (void)hipEventDestroy(sl.st.done);
     if (sl.d_count) (void)hipFree(sl.d_count);
     if (sl.done) (void)hipEventDestroy(sl.done);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -544,6 +652,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
+  else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
   return D2PC_OK;
@@ -556,7 +665,20 @@ int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames) {
   int st = make_geom(ctx, D2PC_DTYPE_U8, 1.f, width, height, size_t(width), size_t(width) * height, n_frames,
                      d2pc_roi_points(width, height, ctx->cfg.border), 4, &g);
   if (st != D2PC_OK) return st;
-  return grow(ctx, &ctx->d_state, &ctx->state_cap, compact_state_bytes(g));
+  // Guarantees ONE free (idle, not owned by a captured graph) buffer of this size, and makes it the
+  // minimum size of every buffer allocated later.  Call it before each capture that contains a COMPACT launch.
+  const size_t need = compact_state_bytes(g);
+  if (need > ctx->state_reserve) ctx->state_reserve = need;
+  StateBuf *pick = nullptr;
+  for (StateBuf &b : ctx->states)
+    if (b.p && !b.captured && state_idle(b) && b.cap >= need) return D2PC_OK;
+  for (StateBuf &b : ctx->states)
+    if (!b.p && !pick) pick = &b;
+  if (!pick)
+    for (StateBuf &b : ctx->states)
+      if (!b.captured && !pick) pick = &b;
+  if (!pick) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "all %d compaction state buffers belong to captured graphs", kMaxStateBufs);
+  return state_alloc(ctx, *pick, need);
 }
 
 int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scale, int width, int height,
@@ -580,26 +702,43 @@ int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scal
     if (d_counts) D2PC_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * size_t(n_frames), s));
     return D2PC_OK;
   }
-  return enqueue(ctx, g, d_disp, dtype, d_out, d_idx, d_counts, s, !stream_is_capturing(s));
+  return enqueue(ctx, g, d_disp, dtype, d_out, d_idx, d_counts, s);
+}
+
+// Reads the header of one state buffer whose last launch was the single pass.
+static int state_timed_out(d2pc_ctx *ctx, const StateBuf &b, bool *timed_out) {
+  *timed_out = false;
+  if (!b.p || b.algo != 2) return D2PC_OK;  // the two-pass form has no in-launch hand-off and never reads the flag
+  StateHeader h;
+  D2PC_HIP(ctx, hipMemcpy(&h, b.p, sizeof h, hipMemcpyDeviceToHost));
+  *timed_out = h.timeout != 0;
+  return D2PC_OK;
 }
 
 int d2pc_check_async_error(d2pc_ctx *ctx) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
-  // only the single-pass algorithm has bounded spins (and zeroes the header)
-  if (!ctx->d_state || ctx->last_compact_algo != 2) return D2PC_OK;
   DeviceGuard guard(ctx->device);
-  StateHeader h;
-  D2PC_HIP(ctx, hipMemcpy(&h, ctx->d_state, sizeof h, hipMemcpyDeviceToHost));
-  if (h.timeout) return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
+  // every buffer remembers the algorithm of ITS last launch: a small two-pass launch after a big single-pass
+  // one (another buffer, or the same one re-used) neither hides the big launch's flag nor inherits a stale one
+  for (const StateBuf &b : ctx->states) {
+    bool bad = false;
+    int st = state_timed_out(ctx, b, &bad);
+    if (st != D2PC_OK) return st;
+    if (bad) return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
+  }
   return D2PC_OK;
 }
 
 #ifdef D2PC_DIAG
 // diagnostic build only: copy the 64-byte state header (phase timers) out
 int d2pc_debug_read_header(d2pc_ctx *ctx, void *out64) {
-  if (!ctx || !ctx->d_state) return D2PC_ERR_INVALID_ARG;
+  const StateBuf *last = nullptr;  // diagnostic runs use one stream: the buffer of the last single-pass launch
+  if (ctx)
+    for (const StateBuf &b : ctx->states)
+      if (b.p && b.algo == 2) last = &b;
+  if (!last) return D2PC_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
-  D2PC_HIP(ctx, hipMemcpy(out64, ctx->d_state, 64, hipMemcpyDeviceToHost));
+  D2PC_HIP(ctx, hipMemcpy(out64, last->p, 64, hipMemcpyDeviceToHost));
   return D2PC_OK;
 }
 #endif
@@ -674,16 +813,24 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
     kernel_in = ctx->d_med;
   }
   D2PC_HIP(ctx, mark(2));
-  st = enqueue(ctx, g, kernel_in, kdtype, ctx->d_out, out_index ? static_cast<uint32_t *>(ctx->d_idx) : nullptr,
-               ctx->d_counts, s, true);
+  uint32_t *kidx = out_index ? static_cast<uint32_t *>(ctx->d_idx) : nullptr;
+  st = enqueue(ctx, g, kernel_in, kdtype, ctx->d_out, kidx, ctx->d_counts, s);
   if (st != D2PC_OK) return st;
   D2PC_HIP(ctx, mark(3));
   size_t n = g.roi_n;
   if (compact) {
     D2PC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     D2PC_HIP(ctx, hipStreamSynchronize(s));
-    if ((st = d2pc_check_async_error(ctx)) != D2PC_OK) return st;
+    if (ctx->h_counts[0] == kCountTimedOut) {
+      // the single pass gave up waiting for a predecessor (only ever selected here by cfg.compact_algo = 2):
+      // this entry point is synchronous, so run the frame again with the two-pass form, which cannot wait
+      st = enqueue(ctx, g, kernel_in, kdtype, ctx->d_out, kidx, ctx->d_counts, s, nullptr, 1);
+      if (st != D2PC_OK) return st;
+      D2PC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      D2PC_HIP(ctx, hipStreamSynchronize(s));
+    }
     n = ctx->h_counts[0];
+    if (n > g.roi_n) return fail(ctx, D2PC_ERR_INTERNAL, "compaction reported %zu points for %u ROI pixels", n, g.roi_n);
     if (n > capacity) return fail(ctx, D2PC_ERR_CAPACITY, "capacity %zu < %zu valid points", capacity, n);
   }
   if (n) {
@@ -885,6 +1032,17 @@ int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
                 slot, sl.roi_n, g.roi_n);
   hipStream_t s = sl.stream;
   const size_t in_bytes = size_t(d.height) * d.row_stride_bytes;
+  // from the first enqueue on, a failure must not hand the slot back while work that reads h_in or
+  // writes h_out is in flight: drain the stream and park the slot as "collected" (release frees it)
+  struct SlotDrain {
+    PipeSlot &sl;
+    bool armed = true;
+    ~SlotDrain() {
+      if (!armed) return;
+      (void)hipStreamSynchronize(sl.stream);
+      sl.state = 3;
+    }
+  } drain{sl};
   D2PC_HIP(ctx, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, s));
   const void *kin = sl.d_in;
   MedianArgs m;
@@ -909,7 +1067,7 @@ int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
     uint32_t *kidx = !d.want_index ? nullptr
                      : ctx->pipe_direct ? reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(sl.h_out) + sl.idx_off)
                                         : static_cast<uint32_t *>(sl.d_idx);
-    st = enqueue(ctx, g, kin, kdtype, kout, kidx, sl.d_count, s, true, &sl.d_state, &sl.d_state_cap);
+    st = enqueue(ctx, g, kin, kdtype, kout, kidx, sl.d_count, s, &sl.st);
     if (st != D2PC_OK) return st;
     D2PC_HIP(ctx, hipMemcpyAsync(sl.h_count, sl.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (!ctx->pipe_direct) {
@@ -922,6 +1080,7 @@ int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
     }
   }
   D2PC_HIP(ctx, hipEventRecord(sl.done, s));
+  drain.armed = false;
   sl.seq = ++ctx->pipe_seq;
   sl.state = 2;
   return D2PC_OK;
@@ -938,14 +1097,10 @@ int d2pc_pipeline_collect(d2pc_ctx *ctx, int *slot, const void **points, const u
   DeviceGuard guard(ctx->device);
   PipeSlot &sl = ctx->slots[oldest];
   D2PC_HIP(ctx, hipEventSynchronize(sl.done));
-  if (ctx->cfg.mode == D2PC_MODE_COMPACT && ctx->last_compact_algo == 2 && sl.d_state) {
-    StateHeader h;
-    D2PC_HIP(ctx, hipMemcpy(&h, sl.d_state, sizeof h, hipMemcpyDeviceToHost));
-    if (h.timeout) {
-      *slot = oldest;  // the frame is lost, but the slot can be released
-      sl.state = 3;
-      return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
-    }
+  if (sl.roi_n && sl.h_count[0] == kCountTimedOut) {  // in-band: the slot's own launch reported it
+    *slot = oldest;  // the frame is lost, but the slot can be released
+    sl.state = 3;
+    return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
   }
   *slot = oldest;
   *points = sl.h_out;

@@ -55,6 +55,7 @@ struct Geom {
   uint64_t out_frame_stride;          // points between frames' outputs
   float scale;                        // U8/U16 decode: d = (float)raw*scale
   float min_disparity;                // compact predicate: drop d <= this
+  uint32_t spin_ticks;                // single pass: hand-off wait budget in s_memrealtime ticks (100 MHz)
 };
 
 // Q_ (reference hpp:72): row-major 4x4 doubles.  Kernarg => scalar registers,
@@ -92,6 +93,12 @@ constexpr uint32_t kFrameTicketBytes = 256;   // the ticket word has a 256-B blo
 constexpr uint32_t kGroupAccStride = 128;     // one group accumulator per 128-B line
 constexpr uint64_t kGranuleTag = uint64_t(1) << 63;
 constexpr int kGroupTiles = 64;         // tiles per counting group
-constexpr uint32_t kSpinLimit = 1u << 18;     // polls with back-off: a fraction of a second
+// Hand-off waits are bounded by TIME (constant 100 MHz clock), not by a poll count: a block holding an
+// earlier ticket can be descheduled for long (several processes on one GPU, CWSR preemption, a debugger),
+// and a healthy launch must not be declared broken for it.  Default 4 s; d2pc_set_tuning("spin_timeout_ms").
+constexpr uint32_t kSpinTicksPerMs = 100000u;
+constexpr uint32_t kDefaultSpinMs = 4000u;
+// counts[f] of a frame whose hand-off timed out: visible in-band, not only through d2pc_check_async_error
+constexpr uint32_t kCountTimedOut = 0xffffffffu;
 
 }  // namespace d2pc

@@ -102,6 +102,11 @@ struct QArg<QK_STEREO> {
   QStereo s;
 };
 
+// cv::reprojectImageTo3D ends every pixel with `if (fabs(d - minDisparity) <= FLT_EPSILON) Z = bigZ`
+// (bigZ = 10000); with handleMissingValues = false (cpp:64) minDisparity stays FLT_MAX, so the test
+// holds for d == FLT_MAX only.  One compare + select; X and Y stay as computed.
+__device__ __forceinline__ float big_z_rule(float d, float Z) { return d == 3.402823466e+38f ? 10000.0f : Z; }
+
 // cpp:63-64  [X Y Z W] = Q.(u,v,d,1); (X/W, Y/W, Z/W) evaluated in fp64 with
 // the association of OpenCV 2.4's loop: (row term + u*q_0) + d*q_2, then
 // iW = 1./W and num*iW, one cast to fp32 at the end.
@@ -116,7 +121,7 @@ __device__ __forceinline__ void reproject(const QArg<QK_GENERAL> &A, uint32_t u,
   const double iw = 1.0 / nw;
   X = float(nx * iw);
   Y = float(ny * iw);
-  Z = float(nz * iw);
+  Z = big_z_rule(d, float(nz * iw));
 }
 
 // Same evaluation with Q = [1 0 0 cx; 0 1 0 cy; 0 0 0 f; 0 0 a b]: the
@@ -130,7 +135,7 @@ __device__ __forceinline__ void reproject(const QArg<QK_STEREO> &A, uint32_t u, 
   const double iw = 1.0 / nw;
   X = float((double(u) + A.s.cx) * iw);
   Y = float((double(v) + A.s.cy) * iw);
-  Z = float(A.s.f * iw);
+  Z = big_z_rule(d, float(A.s.f * iw));
 }
 
 __device__ __forceinline__ bool point_is_valid(float X, float Y, float Z, float d, float min_disparity) {
@@ -417,7 +422,7 @@ __device__ __forceinline__ void backoff(uint32_t spins) {
 // with agent-scope (coherent) loads, with back-off.
 template <bool WAIT, class Ready>
 __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, StateHeader *hdr, uint32_t lane,
-                                                 uint32_t &spin_acc, Ready ready) {
+                                                 uint32_t &spin_acc, uint32_t spin_ticks, Ready ready) {
   using gu64 = __attribute__((address_space(1))) const uint64_t;
   uint64_t v = 0;
   if constexpr (!WAIT) {
@@ -427,17 +432,20 @@ __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, Sta
     if (on) v = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     bool ok = !on || ready(v);
     uint32_t spins = 0;
+    uint64_t t0 = 0;
     while (!__all(ok)) {
+      if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
       backoff(spins);
       if (!ok) {
         v = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = ready(v);
       }
-      // bounded: give up after kSpinLimit polls, and as soon as ANY wave of the
-      // launch has given up (sticky flag), so a broken launch drains in about a
-      // second instead of timing out tile by tile; the host then sees the flag
-      if (++spins > kSpinLimit ||
-          ((spins & 63u) == 0 && __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      // bounded by time: give up once the budget is spent, and as soon as ANY wave of the launch has
+      // given up (sticky flag), so a broken launch drains at once instead of timing out tile by tile
+      ++spins;
+      if ((spins & 15u) == 0 &&
+          (__builtin_amdgcn_s_memrealtime() - t0 > uint64_t(spin_ticks) ||
+           __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         if (lane == 0) __hip_atomic_store(&hdr->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -460,13 +468,14 @@ struct KnownGroups {
 
 template <bool WAIT>
 __device__ __forceinline__ uint32_t prefix_before(const FrameState &fs, StateHeader *hdr, uint32_t lt,
-                                                  uint32_t lane, uint32_t &spin_acc, KnownGroups &known) {
+                                                  uint32_t lane, uint32_t &spin_acc, KnownGroups &known,
+                                                  uint32_t spin_ticks) {
   const uint32_t grp = lt / kGroupTiles;
   uint32_t sum = 0;
   for (uint32_t g0 = known.groups; g0 < grp; g0 += 64) {  // groups below grp hold kGroupTiles tiles each
     const uint32_t gi = g0 + lane;
     const bool on = gi < grp;
-    const uint64_t v = read_counted<WAIT>(fs.group_word(gi), on, hdr, lane, spin_acc,
+    const uint64_t v = read_counted<WAIT>(fs.group_word(gi), on, hdr, lane, spin_acc, spin_ticks,
                                           [](uint64_t x) { return uint32_t(x >> 32) == uint32_t(kGroupTiles); });
     sum += on ? uint32_t(v) : 0u;
   }
@@ -478,7 +487,7 @@ __device__ __forceinline__ uint32_t prefix_before(const FrameState &fs, StateHea
   {  // tiles grp*64 .. lt-1 of the own group (< 64 of them)
     const uint32_t ti = grp * kGroupTiles + lane;
     const bool on = ti < lt;
-    const uint64_t v = read_counted<WAIT>(fs.granules + 2u * ti, on, hdr, lane, spin_acc,
+    const uint64_t v = read_counted<WAIT>(fs.granules + 2u * ti, on, hdr, lane, spin_acc, spin_ticks,
                                           [](uint64_t x) { return (x & kGranuleTag) != 0; });
     sum += on ? uint32_t(v) : 0u;
   }
@@ -775,7 +784,7 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
         // ticket of the tile after `cur`, and the prefix of `prev`
         if (cur != kNoTile && lane == 0) s_next[slot] = atomicAdd(fs.ticket, 1u);
         if (prev2 != kNoTile) {
-          const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, spin_acc, known);
+          const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, spin_acc, known, g.spin_ticks);
           if (lane == 0) s_prefix[slot] = p;
         }
       } else if (cur != kNoTile) {
@@ -829,7 +838,12 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
               if (fidx) store_index(fidx, pos, vv[k] * g.width + uu[k]);
             }
           }
-          if (counts && prev2 == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + qtotal;
+          if (counts && prev2 == g.tiles_per_frame - 1 && tid == 0) {
+            // a frame whose hand-off broke reports kCountTimedOut instead of a count: visible in-band
+            const bool bad = __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            __hip_atomic_store(counts + f, bad ? kCountTimedOut : prefix + qtotal, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
         // prev -> prev2
         qtotal = ptotal;
@@ -866,6 +880,10 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
       cur = next;
     }
     __syncthreads();
+    // a block that saw the launch break marks the frame it was serving (it may have scattered with a
+    // prefix it never obtained), whether or not the frame's last tile has reported its count already
+    if (counts && tid == 0 && __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      __hip_atomic_store(counts + f, kCountTimedOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #ifdef D2PC_DIAG
   if (lane == 0 && wave == 0) {

@@ -176,8 +176,23 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale,
  * to the context's device; d_out_points must be 16-byte aligned -- 128-byte
  * alignment (of the base and of out_frame_stride_points*16) keeps every wave
  * store on whole 64-byte memory requests; a base 16 bytes off costs ~20 %.
- * Does not synchronise.  Call d2pc_reserve first if the call must be
- * capturable into a hipGraph (no allocation happens then).
+ * Does not synchronise.
+ *
+ * COMPACT launches in flight at once: calls on ONE stream are ordered and share
+ * the context's compaction state; a call on another stream gets a state buffer
+ * of its own (up to 8 per context), so double-buffered use of one context on
+ * two streams is safe.  The context itself is still used from one host thread.
+ *
+ * hipGraph capture: call d2pc_reserve(width, height, n_frames) for the largest
+ * batch before EACH capture that contains a COMPACT call -- nothing can be
+ * allocated while capturing (D2PC_ERR_OUT_OF_MEMORY otherwise).  The state
+ * buffer a capture used belongs to that graph from then on: later calls never
+ * free, grow or share it, so the graph stays replayable whatever else the
+ * context is asked to do.  One replay of a given graph in flight at a time.
+ *
+ * COMPACT failure reporting in-band: if the single-pass kernel gave up waiting
+ * for an earlier tile (see d2pc_check_async_error) d_counts[f] of the affected
+ * frames is 0xFFFFFFFF instead of a count.
  */
 int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype,
                         float scale, int width, int height,
@@ -259,14 +274,19 @@ int d2pc_pipeline_collect(d2pc_ctx *ctx, int *slot, const void **points, const u
                           size_t *n_points, uint64_t *tag);
 int d2pc_pipeline_release(d2pc_ctx *ctx, int slot);
 
-/* Pre-size the context's scratch (tile state, staging) for frames up to
- * width x height and batches up to n_frames. */
+/* Guarantee one free compaction-state buffer for frames up to width x height
+ * and batches up to n_frames (and make that the minimum size of any allocated
+ * later).  Needed before a capture; optional otherwise (buffers grow on demand). */
 int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames);
 
-/* After the stream of a COMPACT d2pc_process_device call has been
- * synchronised: D2PC_ERR_INTERNAL if a bounded hand-off wait of the single-pass
- * kernel expired in the last launch (its output is then incomplete; relaunch
- * with compact_algo = 1).  The synchronous entry points check this themselves. */
+/* After the streams of the context's COMPACT d2pc_process_device calls have been
+ * synchronised: D2PC_ERR_INTERNAL if a hand-off wait of the single-pass kernel
+ * ran out of its time budget (default 4 s, tuning "spin_timeout_ms") in the
+ * LAST launch of any of the context's state buffers -- each buffer remembers
+ * the algorithm of its own last launch.  The output of such a launch is
+ * incomplete and its d_counts entries read 0xFFFFFFFF; relaunch with
+ * compact_algo = 1.  d2pc_process* (synchronous) does that relaunch itself;
+ * d2pc_pipeline_collect reports the frame as D2PC_ERR_INTERNAL. */
 int d2pc_check_async_error(d2pc_ctx *ctx);
 
 /*
@@ -349,7 +369,8 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * depend on it).  Keys: "pxt_parity", "pxt_compact" (ROI pixels per thread:
  * 4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by the tile count; 1..4096),
  * "onepass_blocks_per_cu", "force_general_q", "no_vec_rows", "fuse_rows" (rows per wave of
- * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times). */
+ * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
+ * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

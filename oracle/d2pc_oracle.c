@@ -12,6 +12,7 @@
  */
 #include "d2pc_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -87,7 +88,16 @@ typedef struct {
  *   Vec4d h = Q*Vec4d(x,y,d,1)  (row dot products, left to right)
  *   Vec3f p = Vec3d(h.val)      (cast of the numerators to float)
  *   p /= h[3]                   (ia = 1./h[3]; p[i] = (float)(p[i]*ia))
+ *
+ * Both forms end with [upstream, same file]
+ *   if (fabs(d - minDisparity) <= FLT_EPSILON) Z = bigZ;      bigZ = 10000.
+ * where minDisparity stays at its initial FLT_MAX unless handleMissingValues
+ * is set (cpp:64 leaves it false): the test is true only for d == FLT_MAX,
+ * which then gets Z = 10000 (X and Y are left as computed).  Unreachable from
+ * the node (d <= 31.875 after cpp:61), reachable through the fp32 seam.
  */
+#define D2PC_ORACLE_MIN_DISPARITY ((double)FLT_MAX)
+#define D2PC_ORACLE_BIG_Z 10000.
 static void reproject_row(const void *row, int dtype, float scale, int y,
                           int u0, int u1, const double *q, int form,
                           xyz_t *out) {
@@ -101,7 +111,8 @@ static void reproject_row(const void *row, int dtype, float scale, int y,
       const double iW = 1. / (qw + q[14] * d);
       const double X = (qx + q[2] * d) * iW;
       const double Y = (qy + q[6] * d) * iW;
-      const double Z = (qz + q[10] * d) * iW;
+      double Z = (qz + q[10] * d) * iW;
+      if (fabs(d - D2PC_ORACLE_MIN_DISPARITY) <= FLT_EPSILON) Z = D2PC_ORACLE_BIG_Z;
       out[x - u0].x = (float)X;
       out[x - u0].y = (float)Y;
       out[x - u0].z = (float)Z;
@@ -117,6 +128,8 @@ static void reproject_row(const void *row, int dtype, float scale, int y,
       out[x - u0].x = (float)((float)h[0] * ia);
       out[x - u0].y = (float)((float)h[1] * ia);
       out[x - u0].z = (float)((float)h[2] * ia);
+      if (fabs(d - D2PC_ORACLE_MIN_DISPARITY) <= FLT_EPSILON)
+        out[x - u0].z = (float)D2PC_ORACLE_BIG_Z;
     }
   }
 }

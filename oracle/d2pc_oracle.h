@@ -43,7 +43,12 @@ enum { D2PC_ORACLE_F32 = 0, D2PC_ORACLE_U8 = 1, D2PC_ORACLE_U16 = 2 };
  *        one cast to float.
  *  CV4 : OpenCV 3.x/4.x: Vec4d h = Q*(x,y,d,1); Vec3f p = h.xyz (cast);
  *        p /= h[3]  (float * double reciprocal, cast).
- * Both are double-precision evaluations; results differ by <= 2 float ulp. */
+ * Both are double-precision evaluations; results differ by <= 2 float ulp.
+ * Both end with `if (fabs(d - minDisparity) <= FLT_EPSILON) Z = bigZ` where
+ * minDisparity = FLT_MAX and bigZ = 10000 for handleMissingValues = false
+ * (what cpp:64 passes): a pixel with d == FLT_MAX gets Z = 10000.  Restated
+ * here and in the kernel (round 1 omitted it: unreachable from the node,
+ * whose d <= 31.875, but reachable through the fp32 entry). */
 enum { D2PC_ORACLE_FORM_CV24 = 0, D2PC_ORACLE_FORM_CV4 = 1 };
 
 /* hpp:84-104 -- closed form of cv::stereoRectify for the reference's rig

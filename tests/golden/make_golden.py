@@ -26,6 +26,7 @@ from fractions import Fraction
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+FLT_MAX = np.float32(3.4028234663852886e38)
 
 
 def f32_bits(x: float) -> int:
@@ -80,9 +81,10 @@ def exact_points(q, disp, border, rows=None):
             d = Fraction(float(disp[v, u]))
             num = [qf[4 * r] * u + qf[4 * r + 1] * v + qf[4 * r + 2] * d + qf[4 * r + 3] for r in range(4)]
             assert num[3] != 0, "exact W == 0: not a finite known-answer point"
-            out.append(
-                [f32_bits(float(round_fraction_to_f32(num[r] / num[3]))) for r in range(3)] + [0x3F800000]
-            )
+            xyz = [f32_bits(float(round_fraction_to_f32(num[r] / num[3]))) for r in range(3)]
+            if disp[v, u] == FLT_MAX:  # reprojectImageTo3D: |d - minDisparity| <= FLT_EPSILON => Z = bigZ = 10000,
+                xyz[2] = f32_bits(10000.0)  # minDisparity = FLT_MAX when handleMissingValues is false (cpp:64)
+            out.append(xyz + [0x3F800000])
     return np.array(out, dtype=np.uint32).reshape(-1, 4)
 
 
@@ -118,6 +120,17 @@ def main():
     raw = rng.integers(1, 256, size=(243, 752)).astype(np.uint8)
     dd = raw.astype(np.float32) * np.float32(0.125)
     cases["D_centre_rows_u8"] = dict(q=qa, disp=dd, border=0, rows=(238, 243), raw=raw)
+
+    # Case E: the missing-value sentinel.  d == FLT_MAX is the one disparity reprojectImageTo3D treats
+    # specially with handleMissingValues = false: Z = 10000 exactly, X and Y as computed (subnormal or 0
+    # here).  Its float neighbour just below FLT_MAX must NOT get the rule.  Drawn after A-D so those
+    # cases keep their values.
+    below = np.nextafter(FLT_MAX, np.float32(0))
+    pool = np.array([FLT_MAX, below, 1.0, 31.875, FLT_MAX, 0.125], dtype=np.float32)
+    de = pool[rng.integers(0, len(pool), size=(4, 752))]
+    de[0, :4] = [FLT_MAX, below, FLT_MAX, 1.0]
+    cases["E_flt_max_sentinel"] = dict(q=qa, disp=de, border=0)
+    cases["E_flt_max_sentinel_dense_q"] = dict(q=qb.astype(np.float64), disp=de[:, :100].copy(), border=0)
 
     arrays = {}
     for name, c in cases.items():

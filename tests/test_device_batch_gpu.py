@@ -137,3 +137,92 @@ def test_launch_on_side_stream_and_graph_capture(algo):
         assert np.array_equal(i1, wi) and np.array_equal(i2, wi)
         assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32))
         assert_points_close(p1, wp, max_ulp=1)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_two_streams_in_flight_from_one_context_do_not_share_compaction_state(algo):
+    """Double buffering: COMPACT launches of ONE context enqueued on two streams overlap on the device.
+    Each launch must own its tickets / partial counts / granules (round 1 shared one buffer: points came
+    out silently wrong).  Both result sets are checked against the oracle after many overlapping rounds."""
+    q = d2pc.make_q()
+    fa = [synth_disparity(3, 100 + f, 1920, 1080, "holes") for f in range(6)]
+    fb = [synth_disparity(3, 200 + f, 1920, 1080, "blocky") for f in range(6)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+        ba, bb = _batch(ctx, fa, want_index=True), _batch(ctx, fb, want_index=True)
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for _ in range(12):  # no synchronisation in between: launches of the two streams interleave freely
+            ba.launch(stream=sa)
+            bb.launch(stream=sb)
+        torch.cuda.synchronize()
+        ctx.check_async_error()
+        ra, rb = ba.results(), bb.results()
+    for frames, res in ((fa, ra), (fb, rb)):
+        for f, (pts, idx) in enumerate(res):
+            wp, wi = oracle.reproject_compact(frames[f], q, border=40)
+            assert np.array_equal(idx, wi), f"frame {f}"
+            assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"two-stream frame {f}")
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_graph_replay_survives_a_larger_eager_launch(algo):
+    """A captured launch bakes its state pointer into the graph.  A later, LARGER eager launch needs more
+    state: it must get a buffer of its own instead of freeing the graph's (round 1: use-after-free)."""
+    q = d2pc.make_q()
+    small = [synth_disparity(2, f, 640, 480, "holes") for f in range(4)]
+    big = [synth_disparity(3, 300 + f, 1920, 1080, "holes") for f in range(8)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+        bs = _batch(ctx, small, want_index=True)       # reserves state for the small batch only
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            bs.launch()
+        g.replay()
+        torch.cuda.synchronize()
+        from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+
+        bb = DeviceBatch.__new__(DeviceBatch)          # a big batch WITHOUT the constructor's d2pc_reserve
+        cfg = ctx.config()
+        bb.ctx, bb.n_frames, bb.height, bb.width = ctx, len(big), 1080, 1920
+        bb.roi_n = d2pc.roi_points(1920, 1080, cfg.border)
+        bb.stride = (bb.roi_n + 15) // 16 * 16
+        bb.device = torch.device("cuda:0")
+        bb.disp = torch.from_numpy(np.stack(big)).cuda()
+        bb.points = torch.empty((len(big), bb.stride, 4), dtype=torch.float32, device="cuda")
+        bb.index = torch.empty((len(big), bb.stride), dtype=torch.int32, device="cuda")
+        bb.counts = torch.zeros((len(big),), dtype=torch.int32, device="cuda")
+        bb.launch()
+        rbig = bb.results()
+        bs.points.fill_(0)
+        bs.counts.fill_(0)
+        g.replay()                                     # the graph's buffer must still be alive and its own
+        bb.launch()                                    # ... while the eager path keeps using the other one
+        g.replay()
+        rsmall = bs.results()
+        ctx.check_async_error()
+    for frames, res in ((small, rsmall), (big, rbig)):
+        for f, (pts, idx) in enumerate(res):
+            wp, wi = oracle.reproject_compact(frames[f], q, border=40)
+            assert np.array_equal(idx, wi), f"frame {f}"
+            assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"frame {f}")
+
+
+def test_capture_without_a_reserved_state_buffer_fails_cleanly():
+    """Nothing can be allocated during capture: without d2pc_reserve the call must fail with
+    OUT_OF_MEMORY (and say what to do) instead of allocating or touching another launch's buffer."""
+    q = d2pc.make_q()
+    frames = [synth_disparity(2, f, 640, 480, "holes") for f in range(2)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        disp = torch.from_numpy(np.stack(frames)).cuda()
+        n = d2pc.roi_points(640, 480, 40)
+        pts = torch.empty((2, n, 4), dtype=torch.float32, device="cuda")
+        cnt = torch.zeros((2,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        err = None
+        with torch.cuda.graph(g):
+            try:
+                ctx.process_device(disp.data_ptr(), d2pc.DTYPE_F32, 1.0, 640, 480, 640 * 4, 640 * 480 * 4, 2,
+                                   pts.data_ptr(), None, n, cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            except d2pc.D2pcError as e:
+                err = e
+        assert err is not None and "d2pc_reserve" in str(err)

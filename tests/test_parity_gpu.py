@@ -37,7 +37,8 @@ def ctx_for(q, **kw):
 
 
 # ---------------------------------------------------------------- parity mode
-@pytest.mark.parametrize("name", ["A_default_q_k8", "B_dense_q", "C_extremes"])
+@pytest.mark.parametrize("name", ["A_default_q_k8", "B_dense_q", "C_extremes", "E_flt_max_sentinel",
+                                  "E_flt_max_sentinel_dense_q"])
 def test_golden_exact_rational(golden, name):
     q = golden[name + "__q"]
     border = int(golden[name + "__border"])
