@@ -210,7 +210,14 @@ bool capture_info(hipStream_t s, unsigned long long *id) {
 
 bool state_idle(StateBuf &b) {
   if (!b.pending) return true;
-  if (hipEventQuery(b.done) == hipSuccess) {
+  // another stream of this thread may be capturing (that is when a captured launch looks for a free
+  // buffer): an event query is "unsafe" under the global/thread-local capture modes and would
+  // invalidate the capture, so it runs under the relaxed mode; `done` is never part of a capture
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  const hipError_t e = hipEventQuery(b.done);
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (e == hipSuccess) {
     b.pending = false;
     return true;
   }

@@ -702,25 +702,114 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
 // --------------------------------------------------------------------------
 constexpr uint32_t kNoTile = 0xffffffffu;
 
-template <int QK, int PXT>
-__device__ __forceinline__ void tile_validity(const QArg<QK> &Q, const Geom &g, const float (&d)[PXT], uint32_t base,
-                                              uint32_t wave, uint32_t lane, uint64_t (&mask)[PXT]) {
-  uint32_t uu[PXT], vv[PXT];
-  tile_coords<PXT>(uu, vv, g, base, wave, lane);
-#pragma unroll
-  for (int k = 0; k < PXT; ++k) {
-    const uint32_t i = slot_pixel(base, wave, lane, k);
-    bool ok;
-    if constexpr (QK == QK_STEREO) {
-      ok = stereo_point_valid(Q, uu[k], vv[k], d[k], g.min_disparity);
-    } else {
-      float X, Y, Z;
-      reproject(Q, uu[k], vv[k], d[k], X, Y, Z);
-      ok = point_is_valid(X, Y, Z, d[k], g.min_disparity);
-    }
-    mask[k] = __ballot(ok && i < g.roi_n);
-  }
+// W = a*d + b of a stereoRectify-structured Q (the one quantity validity and the point share), and what
+// it says about the point: `safe` => all three coordinates are finite floats; `sliver` => 0 < |W| < w_safe
+// (never seen with real calibrations): only the real arithmetic can tell.
+struct StereoW {
+  double nw;
+  bool safe, sliver;
+};
+__device__ __forceinline__ StereoW stereo_w(const QArg<QK_STEREO> &A, float d) {
+  const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
+  StereoW w;
+  w.nw = fma(A.s.a, double(dsel), A.s.b);
+  const double aw = fabs(w.nw);
+  w.safe = aw >= A.s.w_safe;  // false for NaN
+  w.sliver = !w.safe && aw > 0.0;
+  return w;
 }
+
+// Image coordinates of ROI pixel i (the rare paths that have no stepped coordinates at hand).
+__device__ __forceinline__ void pixel_coords(const Geom &g, uint32_t i, uint32_t &uu, uint32_t &vv) {
+  const uint32_t v = fdiv(i, g.div_roi_w);
+  uu = i - v * g.roi_w + g.border;
+  vv = v + g.border;
+}
+
+// Validity of pixel i with disparity d WITHOUT its coordinates in the common case (count phase of the
+// single pass).  Must decide exactly like point_ok() below, which the scatter phase uses.
+template <int QK>
+__device__ __forceinline__ bool pixel_valid(const QArg<QK> &Q, const Geom &g, uint32_t i, float d) {
+  bool ok;
+  if constexpr (QK == QK_STEREO) {
+    const StereoW w = stereo_w(Q, d);
+    ok = w.safe;
+    if (__builtin_expect(__any(w.sliver), 0)) {
+      uint32_t uu, vv;
+      pixel_coords(g, i, uu, vv);
+      float X, Y, Z;
+      reproject(Q, uu, vv, d, X, Y, Z);
+      const float inf = __builtin_huge_valf();
+      ok = w.safe || (w.sliver && fabsf(X) < inf && fabsf(Y) < inf && fabsf(Z) < inf);
+    }
+  } else {
+    uint32_t uu, vv;
+    pixel_coords(g, i, uu, vv);
+    float X, Y, Z;
+    reproject(Q, uu, vv, d, X, Y, Z);
+    const float inf = __builtin_huge_valf();
+    ok = fabsf(X) < inf && fabsf(Y) < inf && fabsf(Z) < inf;
+  }
+  return ok && !(d <= g.min_disparity);
+}
+
+// The point of a pixel and its validity (scatter phase): same decisions as pixel_valid().
+template <int QK>
+__device__ __forceinline__ bool point_ok(const QArg<QK> &Q, const Geom &g, uint32_t uu, uint32_t vv, float d, float &X,
+                                         float &Y, float &Z) {
+  reproject(Q, uu, vv, d, X, Y, Z);
+  const float inf = __builtin_huge_valf();
+  bool ok;
+  if constexpr (QK == QK_STEREO) {
+    const StereoW w = stereo_w(Q, d);  // the compiler shares W with reproject()
+    ok = w.safe;
+    if (__builtin_expect(__any(w.sliver), 0))
+      ok = w.safe || (w.sliver && fabsf(X) < inf && fabsf(Y) < inf && fabsf(Z) < inf);
+  } else {
+    ok = fabsf(X) < inf && fabsf(Y) < inf && fabsf(Z) < inf;
+  }
+  return ok && !(d <= g.min_disparity);
+}
+
+// A worker wave's disparities of one tile in flight: the raw 16-byte row pieces (VEC) or the decoded
+// slot values.  Issue and finish are separate so that the loads fly across the scatter of an older tile
+// and the block barriers; finish() turns the pieces into the slot layout through the wave's LDS strip.
+template <int DT, int PXT, bool VEC>
+struct TileFetch {
+  v4f q[VEC ? PXT / 4 : 1];
+  float d[VEC ? 1 : PXT];
+  __device__ __forceinline__ void issue(const uint8_t *fin, const Geom &g, uint32_t base, uint32_t wave, uint32_t lane) {
+    if constexpr (VEC) {
+      Walker w4(g, base + wave * 256u + lane * 4u);
+#pragma unroll
+      for (int j = 0; j < PXT / 4; ++j) {
+        const uint32_t off = (w4.v + g.border) * g.row_stride + (w4.u + g.border) * 4u;
+        const uint32_t last4 = g.last_off - 12u;  // the frame's last aligned group
+        q[j] = ld(reinterpret_cast<const v4f *>(fin + (off < last4 ? off : last4)));
+        w4.step(g, g.s1024_v, g.s1024_u);
+      }
+    } else {
+      tile_load_d<DT, PXT, false>(d, fin, g, base, wave, lane, nullptr);
+    }
+  }
+  __device__ __forceinline__ void finish(float (&out)[PXT], uint32_t lane, float *wave_strip) const {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < PXT / 4; ++j) {
+        *reinterpret_cast<v4f *>(wave_strip + lane * 4u) = q[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) out[j * 4 + sl] = wave_strip[uint32_t(sl) * 64u + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PXT; ++k) out[k] = d[k];
+    }
+  }
+};
 
 template <int DT, int QK, int PXT, bool VEC>
 __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *__restrict__ disp,
@@ -730,9 +819,12 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
                                                                  const Geom g, const QArg<QK> Q) {
   using gu64 = __attribute__((address_space(1))) uint64_t;
   constexpr int CELLS = PXT * (kBlock / 64);
+  constexpr uint32_t TILE = uint32_t(kBlock * PXT);
   __shared__ uint32_t s_cnt[CELLS];
-  __shared__ uint32_t s_excl[2][CELLS];  // per-cell exclusive offsets of the tile counted in iteration it
-  __shared__ uint32_t s_total[2], s_next[2], s_prefix[2];
+  // per-cell exclusive offsets and totals of the last three counted tiles: a tile counted in iteration
+  // `it` is scattered in iteration it + 2, so its offsets stay in LDS instead of in registers
+  __shared__ uint32_t s_excl[3][CELLS];
+  __shared__ uint32_t s_total[3], s_next[2], s_prefix[2];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool ctl = wave == kBlock / 64;  // the fifth wave
   D2PC_DECLARE_STRIPS(VEC, wave < kBlock / 64 ? wave : 0u);
@@ -762,36 +854,43 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
                                // predecessor a whole extra iteration to publish before it is polled
     KnownGroups known;  // control wave: prefix of the frame's complete groups seen so far
 
-    float dc[PXT];  // tile `cur`: disparities (loads in flight until the count phase)
-    float dp[PXT], dq[PXT];  // tiles `prev` / `prev2`: disparities, counted and published
-    uint64_t pmask[PXT], qmask[PXT];
-    uint32_t pexcl[PXT], qexcl[PXT];
-    uint32_t ptotal = 0, qtotal = 0;
+    // A worker's whole pipeline state: the disparities of the three tiles in flight.  Validity is
+    // re-derived in the scatter phase by the same arithmetic (no wave masks kept in scalar registers --
+    // 48 of them spilled in the round-1 form), cell offsets wait in LDS.
+    TileFetch<DT, PXT, VEC> fetch;  // tile `cur`: loads in flight until the count phase
+    float dp[PXT], dq[PXT];         // tiles `prev` / `prev2`
 #pragma unroll
-    for (int k = 0; k < PXT; ++k) {
-      dc[k] = dp[k] = dq[k] = 0.f;
-      pmask[k] = qmask[k] = 0;
-      pexcl[k] = qexcl[k] = 0;
-    }
-    if (!ctl && cur != kNoTile)
-      tile_load_d<DT, PXT, VEC>(dc, fin, g, cur * uint32_t(kBlock * PXT), wave, lane, wave_strip);
+    for (int k = 0; k < PXT; ++k) dp[k] = dq[k] = 0.f;
+    if (!ctl && cur != kNoTile) fetch.issue(fin, g, cur * TILE, wave, lane);
 
     for (uint32_t it = 0; cur != kNoTile || prev != kNoTile || prev2 != kNoTile; ++it) {
       const uint32_t slot = it & 1u;
-      uint64_t mask[PXT];
+      const uint32_t ring = it % 3u, ring2 = (it + 1u) % 3u;  // this iteration's tile / the tile two iterations back
+      float dc[PXT];
       D2PC_STAMP(c0);
       if (ctl) {
-        // ticket of the tile after `cur`, and the prefix of `prev`
+        // ticket of the tile after `cur`, and the prefix of `prev2`
         if (cur != kNoTile && lane == 0) s_next[slot] = atomicAdd(fs.ticket, 1u);
         if (prev2 != kNoTile) {
           const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, spin_acc, known, g.spin_ticks);
           if (lane == 0) s_prefix[slot] = p;
         }
       } else if (cur != kNoTile) {
-        tile_validity<QK, PXT>(Q, g, dc, cur * uint32_t(kBlock * PXT), wave, lane, mask);
+        fetch.finish(dc, lane, wave_strip);
+        const uint32_t base = cur * TILE;
+        const uint32_t i0 = base + wave * 256u + lane;
+        const bool ragged = base + TILE > g.roi_n;  // only a frame's last tile
+        uint32_t cnt[PXT];
+#pragma unroll
+        for (int k = 0; k < PXT; ++k) {
+          const uint32_t i = i0 + uint32_t(k >> 2) * 1024u + uint32_t(k & 3) * 64u;
+          bool ok = pixel_valid<QK>(Q, g, i, dc[k]);
+          if (ragged) ok = ok && i < g.roi_n;
+          cnt[k] = uint32_t(__popcll(__ballot(ok)));
+        }
         if (lane == 0) {
 #pragma unroll
-          for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = uint32_t(__popcll(mask[k]));
+          for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = cnt[k];
         }
       }
       D2PC_STAMP(c1);
@@ -800,9 +899,9 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
       if (ctl && cur != kNoTile) {
         uint32_t total;
         const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
-        if (lane < uint32_t(CELLS)) s_excl[slot][lane] = excl;
+        if (lane < uint32_t(CELLS)) s_excl[ring][lane] = excl;
         if (lane == 0) {
-          s_total[slot] = total;
+          s_total[ring] = total;
           // publish: tagged granule (the data is the flag) + group accumulator
           __hip_atomic_store((gu64 *)(fs.granules + 2u * cur), kGranuleTag | total, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
@@ -818,22 +917,25 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
         if (next >= g.tiles_per_frame) next = kNoTile;
       }
       if (!ctl) {
-        // loads of the next tile first: they fly while `prev` is reprojected and scattered
-        float dn[PXT];
-#pragma unroll
-        for (int k = 0; k < PXT; ++k) dn[k] = 0.f;
-        if (next != kNoTile)
-          tile_load_d<DT, PXT, VEC>(dn, fin, g, next * uint32_t(kBlock * PXT), wave, lane, wave_strip);
+        // loads of the next tile first: they fly while `prev2` is reprojected and scattered, and across
+        // the next iteration's barrier-free count set-up
+        if (next != kNoTile) fetch.issue(fin, g, next * TILE, wave, lane);
         if (prev2 != kNoTile) {
           const uint32_t prefix = s_prefix[slot];
+          const uint32_t base = prev2 * TILE;
+          const bool ragged = base + TILE > g.roi_n;
           uint32_t uu[PXT], vv[PXT];
-          tile_coords<PXT>(uu, vv, g, prev2 * uint32_t(kBlock * PXT), wave, lane);
+          tile_coords<PXT>(uu, vv, g, base, wave, lane);
 #pragma unroll
           for (int k = 0; k < PXT; ++k) {
             float X, Y, Z;
-            reproject(Q, uu[k], vv[k], dq[k], X, Y, Z);
-            const uint32_t pos = prefix + qexcl[k] + mbcnt64(qmask[k]);
-            if (((qmask[k] >> lane) & 1) && pos < g.roi_n) {
+            bool ok = point_ok<QK>(Q, g, uu[k], vv[k], dq[k], X, Y, Z);
+            if (ragged) ok = ok && slot_pixel(base, wave, lane, k) < g.roi_n;
+            const uint64_t m = __ballot(ok);
+            const uint32_t pos = prefix + s_excl[ring2][cell_index(k, wave)] + mbcnt64(m);
+            // pos < roi_n always holds for a correct prefix; the guard keeps a stale or timed-out
+            // prefix from ever becoming an out-of-bounds store
+            if (ok && pos < g.roi_n) {
               store_point<D2PC_ONEPASS_STORE_NT != 0>(fout, pos, X, Y, Z);
               if (fidx) store_index(fidx, pos, vv[k] * g.width + uu[k]);
             }
@@ -841,29 +943,15 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
           if (counts && prev2 == g.tiles_per_frame - 1 && tid == 0) {
             // a frame whose hand-off broke reports kCountTimedOut instead of a count: visible in-band
             const bool bad = __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            __hip_atomic_store(counts + f, bad ? kCountTimedOut : prefix + qtotal, __ATOMIC_RELAXED,
+            __hip_atomic_store(counts + f, bad ? kCountTimedOut : prefix + s_total[ring2], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        // prev -> prev2
-        qtotal = ptotal;
 #pragma unroll
         for (int k = 0; k < PXT; ++k) {
           dq[k] = dp[k];
-          qmask[k] = pmask[k];
-          qexcl[k] = pexcl[k];
+          dp[k] = dc[k];
         }
-        if (cur != kNoTile) {
-          ptotal = s_total[slot];
-#pragma unroll
-          for (int k = 0; k < PXT; ++k) {
-            dp[k] = dc[k];
-            pmask[k] = mask[k];
-            pexcl[k] = s_excl[slot][cell_index(k, wave)];
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < PXT; ++k) dc[k] = dn[k];
       }
 #ifdef D2PC_DIAG
       {
@@ -927,6 +1015,16 @@ static hipError_t launch_parity_t(const LaunchArgs &a) {
   return hipGetLastError();
 }
 
+// Zeroes the compaction state ahead of a single-pass launch.  A kernel of our own rather than
+// hipMemsetAsync: inside a captured graph the runtime's memset node did not reliably leave zeroed state
+// for the kernel node behind it on replays (stale tickets and a stale timeout flag on the second replay,
+// MI355X / ROCm 7.2), and a plain kernel node has exactly the ordering and cache behaviour of the
+// kernels around it.
+__global__ __launch_bounds__(256) void k_state_clear(uint4 *__restrict__ p, uint32_t n16) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n16) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+
 template <int DT, int QK, int PXT, bool VEC>
 static hipError_t launch_compact_t(const LaunchArgs &a) {
   const uint8_t *disp = static_cast<const uint8_t *>(a.disp);
@@ -939,8 +1037,8 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
     hipLaunchKernelGGL((k_compact_scatter<DT, QK, PXT, VEC>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, out,
                        a.out_index, a.counts, state, a.geom, make_qarg<QK>(a));
   } else {
-    hipError_t e = hipMemsetAsync(a.state, 0, a.state_bytes, a.stream);
-    if (e != hipSuccess) return e;
+    const uint32_t n16 = uint32_t((a.state_bytes + 15) / 16);  // buffers are allocated in whole MiB
+    hipLaunchKernelGGL(k_state_clear, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(a.state), n16);
     // frame-static assignment: the grid is a multiple of n_frames, or smaller
     uint32_t grid = a.grid;
     if (grid >= a.geom.n_frames) grid -= grid % a.geom.n_frames;

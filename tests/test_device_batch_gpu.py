@@ -129,14 +129,21 @@ def test_launch_on_side_stream_and_graph_capture(algo):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             b.launch()
-        g.replay()
-        g.replay()
-        second = b.results()
-    for (p1, i1), (p2, i2), fr in zip(first, second, frames):
-        wp, wi = oracle.reproject_compact(fr, q, border=40)
-        assert np.array_equal(i1, wi) and np.array_equal(i2, wi)
-        assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32))
-        assert_points_close(p1, wp, max_ulp=1)
+        replays = []
+        for _ in range(3):  # EVERY replay must do the whole job: outputs are wiped in between (round 1 replayed
+            b.points.fill_(0)  # twice over the same buffers, which hid that the runtime's memset node left stale
+            b.index.fill_(0)   # tickets behind and made the second replay a no-op)
+            b.counts.fill_(0)
+            torch.cuda.synchronize()
+            g.replay()
+            replays.append(b.results())
+            ctx.check_async_error()
+    for second in replays:
+        for (p1, i1), (p2, i2), fr in zip(first, second, frames):
+            wp, wi = oracle.reproject_compact(fr, q, border=40)
+            assert np.array_equal(i1, wi) and np.array_equal(i2, wi)
+            assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32))
+            assert_points_close(p1, wp, max_ulp=1)
 
 
 @pytest.mark.parametrize("algo", [1, 2])
