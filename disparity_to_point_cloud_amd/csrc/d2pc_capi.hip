@@ -65,7 +65,7 @@ struct d2pc_ctx {
   // (fast and slow devices agree on 2048-pixel tiles and 2-4 tiles per block)
   int pxt_parity = 8, pxt_compact = 8;
   int blocks_per_cu = 128;
-  int onepass_blocks_per_cu = 4;
+  int onepass_blocks_per_cu = 3;   // resident blocks per CU: 3 x 5 waves fit the kernel's register budget; 4 only adds polling
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
   int no_vec_rows = 0;
@@ -350,6 +350,13 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     // wants few, long-lived blocks (about what is resident), not many short ones
     const uint32_t persistent = uint32_t(ctx->cu_count) * uint32_t(ctx->onepass_blocks_per_cu);
     a.grid = g.total_tiles < persistent ? g.total_tiles : persistent;
+    if (a.grid < g.n_frames) a.compact_algo = 1;  // more frames than blocks: every block serves one frame only
+  }
+  if (a.compact_algo == 1) {  // (the two-pass grid is the default one computed above)
+    uint32_t want2 = uint32_t(ctx->cu_count) * uint32_t(ctx->blocks_per_cu);
+    if (want2 < quarter) want2 = quarter;
+    a.grid = g.total_tiles < want2 ? g.total_tiles : want2;
+    if (a.grid == 0) a.grid = 1;
   }
   a.state_bytes = compact_state_bytes(g);
   StateBuf *sb = nullptr;

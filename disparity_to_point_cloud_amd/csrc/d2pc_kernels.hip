@@ -702,73 +702,124 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
 // --------------------------------------------------------------------------
 constexpr uint32_t kNoTile = 0xffffffffu;
 
-// W = a*d + b of a stereoRectify-structured Q (the one quantity validity and the point share), and what
-// it says about the point: `safe` => all three coordinates are finite floats; `sliver` => 0 < |W| < w_safe
-// (never seen with real calibrations): only the real arithmetic can tell.
-struct StereoW {
-  double nw;
-  bool safe, sliver;
-};
-__device__ __forceinline__ StereoW stereo_w(const QArg<QK_STEREO> &A, float d) {
-  const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
-  StereoW w;
-  w.nw = fma(A.s.a, double(dsel), A.s.b);
-  const double aw = fabs(w.nw);
-  w.safe = aw >= A.s.w_safe;  // false for NaN
-  w.sliver = !w.safe && aw > 0.0;
-  return w;
-}
-
-// Image coordinates of ROI pixel i (the rare paths that have no stepped coordinates at hand).
+// ---- single-pass building blocks: validity and points of one wave's share of a tile -------------------
+// Image coordinates of ROI pixel i (the paths that have no stepped coordinates at hand).
 __device__ __forceinline__ void pixel_coords(const Geom &g, uint32_t i, uint32_t &uu, uint32_t &vv) {
   const uint32_t v = fdiv(i, g.div_roi_w);
   uu = i - v * g.roi_w + g.border;
   vv = v + g.border;
 }
 
-// Validity of pixel i with disparity d WITHOUT its coordinates in the common case (count phase of the
-// single pass).  Must decide exactly like point_ok() below, which the scatter phase uses.
-template <int QK>
-__device__ __forceinline__ bool pixel_valid(const QArg<QK> &Q, const Geom &g, uint32_t i, float d) {
-  bool ok;
-  if constexpr (QK == QK_STEREO) {
-    const StereoW w = stereo_w(Q, d);
-    ok = w.safe;
-    if (__builtin_expect(__any(w.sliver), 0)) {
-      uint32_t uu, vv;
-      pixel_coords(g, i, uu, vv);
-      float X, Y, Z;
-      reproject(Q, uu, vv, d, X, Y, Z);
-      const float inf = __builtin_huge_valf();
-      ok = w.safe || (w.sliver && fabsf(X) < inf && fabsf(Y) < inf && fabsf(Z) < inf);
-    }
-  } else {
-    uint32_t uu, vv;
-    pixel_coords(g, i, uu, vv);
-    float X, Y, Z;
-    reproject(Q, uu, vv, d, X, Y, Z);
-    const float inf = __builtin_huge_valf();
-    ok = fabsf(X) < inf && fabsf(Y) < inf && fabsf(Z) < inf;
-  }
-  return ok && !(d <= g.min_disparity);
+// W = a*d + b of a stereoRectify-structured Q decides validity without the point:
+//   finite and |W| >= w_safe            => every coordinate is a finite float          -> valid
+//   W zero, infinite or NaN (d = +-inf gives +-inf or NaN; no poisoning of d needed)    -> invalid
+//   0 < |W| < w_safe, the "sliver"      => only the real arithmetic can tell (never seen with a real
+//                                          calibration; a tile that holds one takes the exact path)
+__device__ __forceinline__ double stereo_nw(const QArg<QK_STEREO> &A, float d) { return fma(A.s.a, double(d), A.s.b); }
+__device__ __forceinline__ bool finite_nonzero(double x) {
+  return __builtin_isfpclass(x, 0x0008 | 0x0010 | 0x0080 | 0x0100);  // -normal, -subnormal, +subnormal, +normal
 }
 
-// The point of a pixel and its validity (scatter phase): same decisions as pixel_valid().
+// Exact validity of pixel i by the real arithmetic (general Q, and tiles with a sliver).
 template <int QK>
-__device__ __forceinline__ bool point_ok(const QArg<QK> &Q, const Geom &g, uint32_t uu, uint32_t vv, float d, float &X,
-                                         float &Y, float &Z) {
+__device__ __forceinline__ bool pixel_valid_exact(const QArg<QK> &Q, const Geom &g, uint32_t i, float d) {
+  uint32_t uu, vv;
+  pixel_coords(g, i, uu, vv);
+  float X, Y, Z;
   reproject(Q, uu, vv, d, X, Y, Z);
-  const float inf = __builtin_huge_valf();
-  bool ok;
+  return point_is_valid(X, Y, Z, d, g.min_disparity);
+}
+
+// Count phase: per-slot survivor counts of this wave's pixels of the tile at `base`.  Returns whether the
+// tile needs the exact path (the scatter phase two iterations later must then take it as well, so that
+// both phases decide every pixel identically).
+template <int QK, int PXT>
+__device__ __forceinline__ bool tile_count(const QArg<QK> &Q, const Geom &g, const float (&d)[PXT], uint32_t base,
+                                           uint32_t wave, uint32_t lane, uint32_t (&cnt)[PXT]) {
+  const uint32_t i0 = base + wave * 256u + lane;
+  const uint32_t lim = base + uint32_t(kBlock * PXT) > g.roi_n ? g.roi_n : 0xffffffffu;  // ragged: a frame's last tile
+  bool exact = QK != QK_STEREO;
   if constexpr (QK == QK_STEREO) {
-    const StereoW w = stereo_w(Q, d);  // the compiler shares W with reproject()
-    ok = w.safe;
-    if (__builtin_expect(__any(w.sliver), 0))
-      ok = w.safe || (w.sliver && fabsf(X) < inf && fabsf(Y) < inf && fabsf(Z) < inf);
-  } else {
-    ok = fabsf(X) < inf && fabsf(Y) < inf && fabsf(Z) < inf;
+    uint64_t sliver = 0;
+#pragma unroll
+    for (int k = 0; k < PXT; ++k) {
+      const uint32_t i = i0 + uint32_t(k >> 2) * 1024u + uint32_t(k & 3) * 64u;
+      const double nw = stereo_nw(Q, d[k]);
+      const bool fin = finite_nonzero(nw), big = fabs(nw) >= Q.s.w_safe;
+      cnt[k] = uint32_t(__popcll(__ballot(int(fin) & int(big) & int(!(d[k] <= g.min_disparity)) & int(i < lim))));
+      sliver |= __ballot(int(fin) & int(!big));
+    }
+    exact = sliver != 0;
   }
-  return ok && !(d <= g.min_disparity);
+  if (exact) {
+#pragma unroll
+    for (int k = 0; k < PXT; ++k) {
+      const uint32_t i = i0 + uint32_t(k >> 2) * 1024u + uint32_t(k & 3) * 64u;
+      cnt[k] = uint32_t(__popcll(__ballot(pixel_valid_exact<QK>(Q, g, i, d[k]) && i < lim)));
+    }
+  }
+  return exact;
+}
+
+// Scatter phase: the same decisions, the points, and their ordered stores.  prefix + cell_excl[cell] = output
+// position of the first survivor of a slot (frame prefix + the cell's exclusive offset inside the tile).
+// A wave-uniform pointer moved into vector registers: the single-pass kernel runs out of scalar registers,
+// and a spilled scalar base costs a v_readlane pair before every store.  With the base in VGPRs the store
+// address is one v_lshl_add_u64.
+__device__ __forceinline__ uint64_t vgpr_pointer(const void *p) {
+  const uint64_t x = reinterpret_cast<uint64_t>(p);
+  uint32_t lo, hi;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(lo), "=v"(hi) : "s"(uint32_t(x)), "s"(uint32_t(x >> 32)));
+  return (uint64_t(hi) << 32) | lo;
+}
+
+template <int QK, int PXT, bool EXACT, bool IDX>
+__device__ __forceinline__ void tile_scatter_lean(const QArg<QK> &Q, const Geom &g, const float (&d)[PXT],
+                                                  const uint32_t *cell_excl, uint32_t prefix, uint32_t base,
+                                                  uint32_t wave, uint32_t lane, uint64_t fout, uint64_t fidx) {
+  const uint32_t i0 = base + wave * 256u + lane;
+  const uint32_t lim = base + uint32_t(kBlock * PXT) > g.roi_n ? g.roi_n : 0xffffffffu;
+  // image coordinates of the wave's slots first (stepped from slot to slot; rows wrap inside a tile): the
+  // stepping constants are then dead in the arithmetic below, which is short of scalar registers
+  uint32_t uus[PXT], vvs[PXT];
+  tile_coords<PXT>(uus, vvs, g, base, wave, lane);
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    const uint32_t uu = uus[k], vv = vvs[k];
+    const uint32_t i = i0 + uint32_t(k >> 2) * 1024u + uint32_t(k & 3) * 64u;
+    bool ok;
+    double nw = 0.0;
+    float X, Y, Z;
+    if constexpr (QK == QK_STEREO && !EXACT) {
+      nw = stereo_nw(Q, d[k]);
+      ok = int(finite_nonzero(nw)) & int(fabs(nw) >= Q.s.w_safe) & int(!(d[k] <= g.min_disparity)) & int(i < lim);
+    } else {
+      reproject(Q, uu, vv, d[k], X, Y, Z);
+      ok = point_is_valid(X, Y, Z, d[k], g.min_disparity) && i < lim;
+    }
+    const uint64_t m = __ballot(ok);
+    if (m != 0) {  // whole slots of holes (blocky invalid regions) skip the arithmetic and the stores
+      if constexpr (QK == QK_STEREO && !EXACT) {
+        const double iw = 1.0 / nw;
+        X = float((double(uu) + Q.s.cx) * iw);
+        Y = float((double(vv) + Q.s.cy) * iw);
+        Z = big_z_rule(d[k], float(Q.s.f * iw));
+      }
+      // rank among the slot's survivors, accumulated onto the cell's base in the same two instructions
+      const uint32_t cell_base = prefix + cell_excl[cell_index(k, wave)];  // (LDS broadcast read)
+      const uint32_t pos = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), cell_base));
+      // pos < roi_n always holds for a correct prefix; the guard keeps a stale or timed-out prefix from
+      // ever becoming an out-of-bounds store
+      if (ok && pos < g.roi_n) {
+        using gv4f = __attribute__((address_space(1))) v4f;
+        using gu32 = __attribute__((address_space(1))) uint32_t;
+        const v4f p = {X, Y, Z, 1.0f};
+        if (D2PC_ONEPASS_STORE_NT) __builtin_nontemporal_store(p, (gv4f *)(fout + (uint64_t(pos) << 4)));
+        else *(gv4f *)(fout + (uint64_t(pos) << 4)) = p;
+        if constexpr (IDX) *(gu32 *)(fidx + (uint64_t(pos) << 2)) = vv * g.width + uu;
+      }
+    }
+  }
 }
 
 // A worker wave's disparities of one tile in flight: the raw 16-byte row pieces (VEC) or the decoded
@@ -792,24 +843,26 @@ struct TileFetch {
       tile_load_d<DT, PXT, false>(d, fin, g, base, wave, lane, nullptr);
     }
   }
-  __device__ __forceinline__ void finish(float (&out)[PXT], uint32_t lane, float *wave_strip) const {
+  // Lands the tile in the wave's own part of an LDS stage, pixel-linear: PXT/4 pieces of 256 floats.  The
+  // stage IS the pipeline storage: count and scatter phases read their slot values from it (slot k of lane L =
+  // piece k/4, element (k%4)*64 + L), so no tile lives in registers across iterations.
+  __device__ __forceinline__ void finish(float *stage, uint32_t lane) const {
     if constexpr (VEC) {
 #pragma unroll
-      for (int j = 0; j < PXT / 4; ++j) {
-        *reinterpret_cast<v4f *>(wave_strip + lane * 4u) = q[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) out[j * 4 + sl] = wave_strip[uint32_t(sl) * 64u + lane];
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
+      for (int j = 0; j < PXT / 4; ++j) *reinterpret_cast<v4f *>(stage + uint32_t(j) * 256u + lane * 4u) = q[j];
     } else {
 #pragma unroll
-      for (int k = 0; k < PXT; ++k) out[k] = d[k];
+      for (int k = 0; k < PXT; ++k) stage[uint32_t(k >> 2) * 256u + uint32_t(k & 3) * 64u + lane] = d[k];
     }
   }
 };
+
+// A wave's slot values of a staged tile (LDS is in-order per wave: the wave's own earlier writes are visible).
+template <int PXT>
+__device__ __forceinline__ void stage_read(float (&d)[PXT], const float *stage, uint32_t lane) {
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) d[k] = stage[uint32_t(k >> 2) * 256u + uint32_t(k & 3) * 64u + lane];
+}
 
 template <int DT, int QK, int PXT, bool VEC>
 __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *__restrict__ disp,
@@ -827,7 +880,11 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
   __shared__ uint32_t s_total[3], s_next[2], s_prefix[2];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool ctl = wave == kBlock / 64;  // the fifth wave
-  D2PC_DECLARE_STRIPS(VEC, wave < kBlock / 64 ? wave : 0u);
+  // the disparities of the four tiles a block has in flight (being fetched / counted / waiting / scattered):
+  // 4 stages x 4 worker waves x PXT/4 pieces x 1 KiB; every wave touches its own part only (no barrier)
+  constexpr uint32_t kWaveStage = uint32_t(PXT / 4) * 256u, kStage = (kBlock / 64) * kWaveStage;
+  __shared__ float s_tile[4 * kStage];
+  float *const my_tile = s_tile + (wave < kBlock / 64 ? wave : 0u) * kWaveStage;
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
   uint32_t spin_acc = 0;
 #ifdef D2PC_DIAG
@@ -839,7 +896,8 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
 #define D2PC_STAMP(x)
 #endif
 
-  for (uint32_t f = blockIdx.x % g.n_frames; f < g.n_frames; f += gridDim.x) {
+  {  // a block serves ONE frame (the launcher sizes the grid to a multiple of n_frames)
+    const uint32_t f = blockIdx.x % g.n_frames;
     const FrameState fs(state, g, f);
     const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
     float4 *fout = out + uint64_t(f) * g.out_frame_stride;
@@ -857,37 +915,34 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
     // A worker's whole pipeline state: the disparities of the three tiles in flight.  Validity is
     // re-derived in the scatter phase by the same arithmetic (no wave masks kept in scalar registers --
     // 48 of them spilled in the round-1 form), cell offsets wait in LDS.
-    TileFetch<DT, PXT, VEC> fetch;  // tile `cur`: loads in flight until the count phase
-    float dp[PXT], dq[PXT];         // tiles `prev` / `prev2`
-#pragma unroll
-    for (int k = 0; k < PXT; ++k) dp[k] = dq[k] = 0.f;
-    if (!ctl && cur != kNoTile) fetch.issue(fin, g, cur * TILE, wave, lane);
+    TileFetch<DT, PXT, VEC> fetch;     // tile `next`: issued as soon as its ticket is known (after barrier 1),
+                                       // landed in its LDS stage after barrier 2
+    bool cexact = false, pexact = false, qexact = false;  // does the tile take the exact path (see tile_count)
+    const uint64_t vout = vgpr_pointer(fout), vidx = vgpr_pointer(fidx);
+    if (!ctl && cur != kNoTile) {
+      fetch.issue(fin, g, cur * TILE, wave, lane);
+      fetch.finish(my_tile, lane);  // iteration 0 counts stage 0
+    }
 
     for (uint32_t it = 0; cur != kNoTile || prev != kNoTile || prev2 != kNoTile; ++it) {
       const uint32_t slot = it & 1u;
       const uint32_t ring = it % 3u, ring2 = (it + 1u) % 3u;  // this iteration's tile / the tile two iterations back
-      float dc[PXT];
       D2PC_STAMP(c0);
       if (ctl) {
-        // ticket of the tile after `cur`, and the prefix of `prev2`
-        if (cur != kNoTile && lane == 0) s_next[slot] = atomicAdd(fs.ticket, 1u);
+        // ticket of the tile after `cur` and the prefix of `prev2`: the atomic's round trip (2-3 us under a
+        // saturating write stream) runs under the polls, its result is only needed at the barrier
+        uint32_t tk = 0;
+        if (cur != kNoTile && lane == 0) tk = atomicAdd(fs.ticket, 1u);
         if (prev2 != kNoTile) {
           const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, spin_acc, known, g.spin_ticks);
           if (lane == 0) s_prefix[slot] = p;
         }
+        if (cur != kNoTile && lane == 0) s_next[slot] = tk;
       } else if (cur != kNoTile) {
-        fetch.finish(dc, lane, wave_strip);
-        const uint32_t base = cur * TILE;
-        const uint32_t i0 = base + wave * 256u + lane;
-        const bool ragged = base + TILE > g.roi_n;  // only a frame's last tile
+        float dc[PXT];
+        stage_read<PXT>(dc, my_tile + (it & 3u) * kStage, lane);
         uint32_t cnt[PXT];
-#pragma unroll
-        for (int k = 0; k < PXT; ++k) {
-          const uint32_t i = i0 + uint32_t(k >> 2) * 1024u + uint32_t(k & 3) * 64u;
-          bool ok = pixel_valid<QK>(Q, g, i, dc[k]);
-          if (ragged) ok = ok && i < g.roi_n;
-          cnt[k] = uint32_t(__popcll(__ballot(ok)));
-        }
+        cexact = tile_count<QK, PXT>(Q, g, dc, cur * TILE, wave, lane, cnt);
         if (lane == 0) {
 #pragma unroll
           for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = cnt[k];
@@ -896,6 +951,14 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
       D2PC_STAMP(c1);
       __syncthreads();
       D2PC_STAMP(c2);
+      uint32_t next = kNoTile;
+      if (cur != kNoTile) {
+        next = s_next[slot];
+        if (next >= g.tiles_per_frame) next = kNoTile;
+      }
+      // the next tile's loads go out the moment its ticket is known; they fly while the control wave scans
+      // and publishes
+      if (!ctl && next != kNoTile) fetch.issue(fin, g, next * TILE, wave, lane);
       if (ctl && cur != kNoTile) {
         uint32_t total;
         const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
@@ -911,34 +974,22 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
       }
       __syncthreads();
       D2PC_STAMP(c3);
-      uint32_t next = kNoTile;
-      if (cur != kNoTile) {
-        next = s_next[slot];
-        if (next >= g.tiles_per_frame) next = kNoTile;
-      }
       if (!ctl) {
-        // loads of the next tile first: they fly while `prev2` is reprojected and scattered, and across
-        // the next iteration's barrier-free count set-up
-        if (next != kNoTile) fetch.issue(fin, g, next * TILE, wave, lane);
+        // the tile counted in iteration it + 1 lands in stage (it + 1) % 4, whose previous tenant (counted in
+        // iteration it - 3) was scattered an iteration ago by this same wave
+        if (next != kNoTile) fetch.finish(my_tile + ((it + 1u) & 3u) * kStage, lane);
         if (prev2 != kNoTile) {
+          float dq[PXT];
+          stage_read<PXT>(dq, my_tile + ((it + 2u) & 3u) * kStage, lane);  // counted in iteration it - 2
           const uint32_t prefix = s_prefix[slot];
-          const uint32_t base = prev2 * TILE;
-          const bool ragged = base + TILE > g.roi_n;
-          uint32_t uu[PXT], vv[PXT];
-          tile_coords<PXT>(uu, vv, g, base, wave, lane);
-#pragma unroll
-          for (int k = 0; k < PXT; ++k) {
-            float X, Y, Z;
-            bool ok = point_ok<QK>(Q, g, uu[k], vv[k], dq[k], X, Y, Z);
-            if (ragged) ok = ok && slot_pixel(base, wave, lane, k) < g.roi_n;
-            const uint64_t m = __ballot(ok);
-            const uint32_t pos = prefix + s_excl[ring2][cell_index(k, wave)] + mbcnt64(m);
-            // pos < roi_n always holds for a correct prefix; the guard keeps a stale or timed-out
-            // prefix from ever becoming an out-of-bounds store
-            if (ok && pos < g.roi_n) {
-              store_point<D2PC_ONEPASS_STORE_NT != 0>(fout, pos, X, Y, Z);
-              if (fidx) store_index(fidx, pos, vv[k] * g.width + uu[k]);
-            }
+          const uint32_t *cell_base = s_excl[ring2];
+          if (qexact) {  // (a tile with a sliver, or a general Q: rare / not the calibrated case -- one code copy)
+            if (fidx) tile_scatter_lean<QK, PXT, true, true>(Q, g, dq, cell_base, prefix, prev2 * TILE, wave, lane, vout, vidx);
+            else tile_scatter_lean<QK, PXT, true, false>(Q, g, dq, cell_base, prefix, prev2 * TILE, wave, lane, vout, vidx);
+          } else if (fidx) {
+            tile_scatter_lean<QK, PXT, false, true>(Q, g, dq, cell_base, prefix, prev2 * TILE, wave, lane, vout, vidx);
+          } else {
+            tile_scatter_lean<QK, PXT, false, false>(Q, g, dq, cell_base, prefix, prev2 * TILE, wave, lane, vout, vidx);
           }
           if (counts && prev2 == g.tiles_per_frame - 1 && tid == 0) {
             // a frame whose hand-off broke reports kCountTimedOut instead of a count: visible in-band
@@ -947,11 +998,8 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
                                __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-#pragma unroll
-        for (int k = 0; k < PXT; ++k) {
-          dq[k] = dp[k];
-          dp[k] = dc[k];
-        }
+        qexact = pexact;
+        pexact = cexact;
       }
 #ifdef D2PC_DIAG
       {
@@ -1039,9 +1087,11 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
   } else {
     const uint32_t n16 = uint32_t((a.state_bytes + 15) / 16);  // buffers are allocated in whole MiB
     hipLaunchKernelGGL(k_state_clear, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(a.state), n16);
-    // frame-static assignment: the grid is a multiple of n_frames, or smaller
+    // frame-static assignment: a block serves frame blockIdx % n_frames, so the grid is a multiple of
+    // n_frames (the C ABI falls back to the two-pass form when there are more frames than blocks)
     uint32_t grid = a.grid;
-    if (grid >= a.geom.n_frames) grid -= grid % a.geom.n_frames;
+    if (grid < a.geom.n_frames) return hipErrorInvalidValue;
+    grid -= grid % a.geom.n_frames;
     hipLaunchKernelGGL((k_compact_onepass<DT, QK, PXT, VEC>), dim3(grid), dim3(kBlock + 64), 0, a.stream, disp, out,
                        a.out_index, a.counts, state, a.geom, make_qarg<QK>(a));
   }

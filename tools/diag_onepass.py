@@ -7,15 +7,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from disparity_to_point_cloud_amd import capi
-capi._LIB_NAME = "libd2pc_diag.so"
+capi._LIB_NAME = 'libd2pc_%s.so' % (sys.argv[1] if len(sys.argv) > 1 else 'diag')
 import disparity_to_point_cloud_amd as d2pc
 from disparity_to_point_cloud_amd.torch_api import DeviceBatch
 
 lib = d2pc.load_library()
 hip = ctypes.CDLL("libamdhip64.so.7")
 q = d2pc.make_q()
-for pxt in (8, 16):
-    for bpc in (2, 3, 5):
+for pxt in (8,):
+    for bpc in (3, 4, 5):
         ctx = d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=2)
         ctx.set_tuning("pxt_compact", pxt); ctx.set_tuning("onepass_blocks_per_cu", bpc)
         b = DeviceBatch(ctx, 16, 2160, 3840)
