@@ -383,6 +383,28 @@ def main():
                 c2.check_async_error()
             del b2
             c2.close()
+        # config 3's own geometry: 1920x1080, ~30 % invalid (iid), COMPACT with indices -- one frame (the
+        # two-pass form: count -> scan -> scatter) and a 32-frame batch (the single pass)
+        W3, H3 = 1920, 1080
+        for name, nfr in (("compact_1080p_30pct_holes_index_1frame", 1), ("compact_1080p_30pct_holes_index_32frames", 32)):
+            c2 = d2pc.Context(device_id=local_rank, border=40, mode=d2pc.MODE_COMPACT, q=q)
+            b2 = DeviceBatch(c2, nfr, H3, W3, want_index=True, device=dev)
+            for f in range(nfr):
+                b2.disp[f].copy_(torch.from_numpy(synth_disparity(3, f, W3, H3, "holes")))
+            b2.launch()
+            torch.cuda.synchronize()
+            npts = int(b2.counts.sum().item())
+            _, kms = timed_steps(b2, max(a.steps // 2, 20), 5, lambda: None)
+            ab = algorithmic_bytes(b2, npts, True)
+            variants[name] = {"Mpixels_per_s": round(nfr * W3 * H3 / (kms * 1e-3) / 1e6, 1),
+                              "achieved_GBs": round(ab / (kms * 1e-3) / 1e9, 1),
+                              "frac": round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "ms_per_launch": round(kms, 4), "points_per_launch": npts,
+                              "what": "config 3 geometry; " + ("k_compact_count + k_compact_scan + k_compact_scatter"
+                                                               if nfr == 1 else "k_state_clear + k_compact_onepass")}
+            c2.check_async_error()
+            del b2
+            c2.close()
         # the whole device-resident callback body (cpp:55-85): 8-bit disparity ->
         # median 11x11 -> x1/8 -> reproject + pack, same 16 x 4K geometry
         c3 = d2pc.Context(device_id=local_rank, border=a.border, mode=d2pc.MODE_PARITY, q=q)

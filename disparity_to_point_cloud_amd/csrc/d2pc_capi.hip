@@ -65,7 +65,7 @@ struct d2pc_ctx {
   // (fast and slow devices agree on 2048-pixel tiles and 2-4 tiles per block)
   int pxt_parity = 8, pxt_compact = 8;
   int blocks_per_cu = 128;
-  int onepass_blocks_per_cu = 3;   // resident blocks per CU: 3 x 5 waves fit the kernel's register budget; 4 only adds polling
+  int onepass_blocks_per_cu = 4;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each): 4 fit; sweep in profiles/r02_ab_onepass.txt
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
   int no_vec_rows = 0;
