@@ -415,14 +415,15 @@ def main():
 
         class _Body:
             def launch(self):
-                c3.median_device(raw.data_ptr(), W4K, H4K, W4K, W4K * H4K, a.frames, b3.disp.data_ptr(), W4K,
-                                 W4K * H4K, 11, s3)
+                # cpp:55-57 for the pixels cpp:70-76 read: the ROI-only median (d2pc_median_roi_device)
+                c3.median_roi_device(raw.data_ptr(), W4K, H4K, W4K, W4K * H4K, a.frames, b3.disp.data_ptr(), W4K,
+                                     W4K * H4K, 11, s3)
                 b3.launch(scale=0.125)
 
         _, kms = timed_steps(_Body(), max(a.steps // 8, 5), 3, lambda: None)
         variants["callback_u8_median11_parity_border40"] = {
             "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": round(kms, 4),
-            "what": "k_median_u8<11> + k_reproject_pack<U8> per step"}
+            "what": "k_median_u8<11> over the inset ROI + k_reproject_pack<U8> per step"}
         b3.disp.copy_(raw)
         _, kms = timed_steps(b3, max(a.steps // 4, 5), 3, lambda: None)
         ab = a.frames * b3.roi_n * 17

@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "d2pc_pipeline_configure", "d2pc_pipeline_acquire", "d2pc_pipeline_submit", "d2pc_pipeline_collect",
     "d2pc_pipeline_release", "d2pc_fuse_desc_init", "d2pc_fuse_device", "d2pc_crop_to_square",
     "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16", "d2pc_last_stage_times",
+    "d2pc_median_roi_device",
 ]
 # d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
 (FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
@@ -143,6 +144,8 @@ def load_library():
                                       ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, vp, ctypes.c_size_t, vp,
                                       vp]
     L.d2pc_median_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                     vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp]
+    L.d2pc_median_roi_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
                                      vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp]
     L.d2pc_process_mono8.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_float,
                                      vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
@@ -397,6 +400,13 @@ class Context:
         self._check(self._L.d2pc_median_device(self._h, d_src_ptr, width, height, src_row_stride, src_frame_stride,
                                                n_frames, d_dst_ptr, dst_row_stride, dst_frame_stride, ksize,
                                                stream_ptr))
+
+    def median_roi_device(self, d_src_ptr, width, height, src_row_stride, src_frame_stride, n_frames, d_dst_ptr,
+                          dst_row_stride, dst_frame_stride, ksize=11, stream_ptr=None):
+        """d2pc_median_roi_device: the same filter, computed for the context's inset ROI only."""
+        self._check(self._L.d2pc_median_roi_device(self._h, d_src_ptr, width, height, src_row_stride,
+                                                   src_frame_stride, n_frames, d_dst_ptr, dst_row_stride,
+                                                   dst_frame_stride, ksize, stream_ptr))
 
     def fuse_device(self, desc: "FuseDesc", stream_ptr=None):
         """d2pc_fuse_device: fusion rule + combined confidence + 3x3 median + crop on device planes."""

@@ -34,6 +34,11 @@ struct MedianArgs {
   uint32_t width = 0, height = 0, n_frames = 1;
   uint32_t src_row_stride = 0, dst_row_stride = 0;  // bytes
   uint64_t src_frame_stride = 0, dst_frame_stride = 0;
+  // Output rectangle (median only): pixels [out_x0, out_x0+out_w) x [out_y0, out_y0+out_h) of dst are
+  // written, the rest of dst is left untouched; the window still reads the WHOLE image (replicated only
+  // at the true image edges).  out_w == 0 means the whole image.  The fused callback entry points pass the
+  // inset ROI (cpp:70,72 read nothing else of the filtered image).
+  uint32_t out_x0 = 0, out_y0 = 0, out_w = 0, out_h = 0;
   uint32_t tiles_x = 0, tiles_y = 0;                // filled by launch_median
 };
 bool median_ksize_supported(int k);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const ui
   const uint32_t f = b / (a.tiles_x * a.tiles_y);
   b -= f * a.tiles_x * a.tiles_y;
   const uint32_t ty = b / a.tiles_x, tx = b - ty * a.tiles_x;
-  const int c0 = int(tx) * S::TW, y0 = int(ty) * S::TH;
+  const int c0 = int(a.out_x0) + int(tx) * S::TW, y0 = int(a.out_y0) + int(ty) * S::TH;
   const uint8_t *fsrc = src + uint64_t(f) * a.src_frame_stride;
   uint8_t *fdst = dst + uint64_t(f) * a.dst_frame_stride;
 
@@ -183,11 +183,11 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const ui
       }
     }
     const uint32_t oy = uint32_t(y0) + y, ox = uint32_t(c0) + x;
-    if (oy < a.height) {
+    if (oy < a.out_y0 + a.out_h) {
       uint8_t *o = fdst + uint64_t(oy) * a.dst_row_stride + ox;
 #pragma unroll
       for (int q = 0; q < NPX; ++q)
-        if (ox + uint32_t(q) < a.width) o[q] = uint8_t(-acc[q]);
+        if (ox + uint32_t(q) < a.out_x0 + a.out_w) o[q] = uint8_t(-acc[q]);
     }
   }
 }
@@ -245,8 +245,14 @@ namespace {
 template <int KS>
 hipError_t launch_k(const uint8_t *s, uint8_t *d, MedianArgs a, hipStream_t stream) {
   using S = MedianShape<KS>;
-  a.tiles_x = (a.width + S::TW - 1) / S::TW;
-  a.tiles_y = (a.height + S::TH - 1) / S::TH;
+  if (a.out_w == 0 || a.out_h == 0) {  // whole image
+    a.out_x0 = a.out_y0 = 0;
+    a.out_w = a.width;
+    a.out_h = a.height;
+  }
+  if (a.out_x0 + a.out_w > a.width || a.out_y0 + a.out_h > a.height) return hipErrorInvalidValue;
+  a.tiles_x = (a.out_w + S::TW - 1) / S::TW;
+  a.tiles_y = (a.out_h + S::TH - 1) / S::TH;
   const uint64_t blocks = uint64_t(a.tiles_x) * a.tiles_y * a.n_frames;
   if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_median_u8<KS>, dim3(uint32_t(blocks)), dim3(S::THREADS), 0, stream, s, d, a);

@@ -33,6 +33,30 @@ def test_median_matches_oracle(k, w, h):
         assert np.array_equal(g, oracle.median_u8(img, k))
 
 
+@pytest.mark.parametrize("k", [3, 11])
+@pytest.mark.parametrize("w,h,border", [(752, 480, 40), (97, 131, 7), (100, 90, 40), (82, 81, 40), (64, 64, 0),
+                                        (90, 200, 44), (3840, 2160, 40), (80, 80, 40), (30, 200, 20)])
+def test_median_roi_only_equals_the_whole_image_filter_inside_the_roi(k, w, h, border):
+    """The fused entry points filter only what cpp:70,72 read afterwards.  Inside the inset ROI every pixel must
+    equal the whole-image median (windows still reach the true image edges); outside nothing is written."""
+    rng = np.random.default_rng(w * 7 + h + k + border)
+    imgs = [rng.integers(0, 256, size=(h, w)).astype(np.uint8) for _ in range(2)]
+    src = torch.from_numpy(np.stack(imgs)).cuda()
+    dst = torch.full_like(src, 77)
+    with d2pc.Context(q=d2pc.make_q(), border=border) as ctx:
+        ctx.median_roi_device(src.data_ptr(), w, h, w, w * h, 2, dst.data_ptr(), w, w * h, k,
+                              torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    inside = np.zeros((h, w), dtype=bool)
+    if w > 2 * border and h > 2 * border:
+        inside[border:h - border, border:w - border] = True
+    for g, img in zip(got, imgs):
+        want = oracle.median_u8(img, k)
+        assert np.array_equal(g[inside], want[inside])
+        assert np.all(g[~inside] == 77), "pixels outside the ROI must not be written"
+
+
 def test_median_4k_batch_and_constant_images():
     rng = np.random.default_rng(2)
     a = rng.integers(0, 256, size=(2160, 3840)).astype(np.uint8)

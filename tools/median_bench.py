@@ -31,10 +31,13 @@ for (w, h, n) in ((752, 480, 64), (1920, 1080, 16), (3840, 2160, 16)):
     for k in (3, 11):
         us = t(lambda: ctx.median_device(raw.data_ptr(), w, h, w, w * h, n, b.disp.data_ptr(), w, w * h, k, s))
         print(f"{w}x{h} x{n}: median{k:2d} {us:8.1f} us  = {us/n:7.2f} us/frame  {n*w*h/us:9.1f} Mpix/s", flush=True)
+        ur = t(lambda: ctx.median_roi_device(raw.data_ptr(), w, h, w, w * h, n, b.disp.data_ptr(), w, w * h, k, s))
+        print(f"{w}x{h} x{n}: median{k:2d} ROI only (border 40) {ur:8.1f} us  = {ur/n:7.2f} us/frame  ({100*(1-ur/us):.1f} % less; "
+              f"ROI is {100*(1-(w-80)*(h-80)/(w*h)):.1f} % fewer pixels)", flush=True)
     def body():
-        ctx.median_device(raw.data_ptr(), w, h, w, w * h, n, b.disp.data_ptr(), w, w * h, 11, s)
+        ctx.median_roi_device(raw.data_ptr(), w, h, w, w * h, n, b.disp.data_ptr(), w, w * h, 11, s)
         b.launch(scale=0.125)
     us = t(body)
     us_r = t(lambda: b.launch(scale=0.125))
-    print(f"{w}x{h} x{n}: callback body (median11 + reproject u8) {us:8.1f} us = {us/n:7.2f} us/frame {n*w*h/us:9.1f} Mpix/s; reproject alone {us_r:8.1f} us", flush=True)
+    print(f"{w}x{h} x{n}: callback body (ROI median11 + reproject u8) {us:8.1f} us = {us/n:7.2f} us/frame {n*w*h/us:9.1f} Mpix/s; reproject alone {us_r:8.1f} us", flush=True)
     ctx.close()
