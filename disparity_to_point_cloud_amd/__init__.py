@@ -9,6 +9,7 @@ GPU is usable, calls raise.
 """
 from .capi import (  # noqa: F401
     D2pcError,
+    PinnedBuffer,
     Context,
     DTYPE_F32,
     DTYPE_U8,
@@ -25,6 +26,10 @@ from .capi import (  # noqa: F401
     load_library,
     make_q,
     make_q_disparity_image,
+    make_q_flavour,
+    STEREORECTIFY_CONTINUOUS,
+    STEREORECTIFY_CV24,
+    STEREORECTIFY_CV3,
     roi_points,
     status_string,
     FuseDesc,

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "d2pc_pipeline_configure", "d2pc_pipeline_acquire", "d2pc_pipeline_submit", "d2pc_pipeline_collect",
     "d2pc_pipeline_release", "d2pc_fuse_desc_init", "d2pc_fuse_device", "d2pc_crop_to_square",
     "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16", "d2pc_last_stage_times",
-    "d2pc_median_roi_device",
+    "d2pc_median_roi_device", "d2pc_host_alloc", "d2pc_host_free", "d2pc_make_q_flavour",
 ]
 # d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
 (FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
@@ -82,6 +82,30 @@ class StageTimes(ctypes.Structure):
                 ("d2h_ms", ctypes.c_float), ("total_ms", ctypes.c_float)]
 
 
+class PinnedBuffer:
+    """Page-locked host memory from d2pc_host_alloc with a numpy view (d2pc_process* stores the cloud
+    straight into such a buffer).  Freed when the object is collected or close()d."""
+
+    def __init__(self, shape, dtype):
+        self._L = load_library()
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = self._L.d2pc_host_alloc(max(nbytes, 1))
+        if not self.ptr:
+            raise MemoryError(f"d2pc_host_alloc({nbytes}) failed")
+        buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._L.d2pc_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+
 class D2pcError(RuntimeError):
     def __init__(self, status, message=""):
         self.status = status
@@ -119,6 +143,7 @@ def load_library():
     L.d2pc_status_string.restype = cp
     L.d2pc_device_count.restype = ctypes.c_int
     L.d2pc_make_q.argtypes = [ctypes.c_double] * 5 + [ctypes.c_int, ctypes.c_int, dp]
+    L.d2pc_make_q_flavour.argtypes = [ctypes.c_double] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
     L.d2pc_make_q_disparity_image.argtypes = [ctypes.c_double] * 4 + [dp]
     L.d2pc_set_min_disparity.argtypes = [vp, ctypes.c_float]
     L.d2pc_calib_pack.argtypes = [dp, ctypes.c_int, ctypes.c_int, vp]
@@ -154,6 +179,10 @@ def load_library():
     L.d2pc_mono16_to_mono8_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
                                               ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
     L.d2pc_last_stage_times.argtypes = [vp, ctypes.POINTER(StageTimes)]
+    L.d2pc_host_alloc.argtypes = [ctypes.c_size_t]
+    L.d2pc_host_alloc.restype = ctypes.c_void_p
+    L.d2pc_host_free.argtypes = [vp]
+    L.d2pc_host_free.restype = None
     L.d2pc_pipeline_configure.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.d2pc_pipeline_acquire.argtypes = [vp, ctypes.POINTER(FrameDesc), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     L.d2pc_pipeline_submit.argtypes = [vp, ctypes.c_int]
@@ -203,6 +232,21 @@ def make_q(fx=714.24, fy=713.5, cx=376.0, cy=240.0, baseline=0.09, nx=752, ny=48
                                     q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     if st:
         raise D2pcError(st, "d2pc_make_q")
+    return q
+
+
+STEREORECTIFY_CONTINUOUS, STEREORECTIFY_CV24, STEREORECTIFY_CV3 = 0, 1, 2
+
+
+def make_q_flavour(fx=714.24, fy=713.5, cx=376.0, cy=240.0, baseline=0.09, nx=752, ny=480,
+                   flavour=STEREORECTIFY_CV24) -> np.ndarray:
+    """d2pc_make_q_flavour: the closed form of hpp:104 with a release's corner / centre convention."""
+    q = np.zeros(16, dtype=np.float64)
+    st = load_library().d2pc_make_q_flavour(ctypes.c_double(fx), ctypes.c_double(fy), ctypes.c_double(cx),
+                                            ctypes.c_double(cy), ctypes.c_double(baseline), nx, ny, flavour,
+                                            q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    if st:
+        raise D2pcError(st, "d2pc_make_q_flavour")
     return q
 
 
@@ -334,8 +378,9 @@ class Context:
         self._check(self._L.d2pc_check_async_error(self._h))
 
     # -- hot path: host buffers (d2pc_process) ------------------------------
-    def process(self, disp: np.ndarray, scale=1.0, want_index=False, capacity=None):
-        """(H,W) numpy disparity -> ((n,4) float32 points[, (n,) uint32 index])."""
+    def process(self, disp: np.ndarray, scale=1.0, want_index=False, capacity=None, out=None, out_index=None):
+        """(H,W) numpy disparity -> ((n,4) float32 points[, (n,) uint32 index]).  `out` / `out_index`: caller
+        buffers to fill (e.g. PinnedBuffer(...).array, which the kernels then store into directly)."""
         if disp.ndim != 2 or disp.strides[1] != disp.itemsize:
             raise ValueError("disp must be a 2-D array with contiguous rows")
         dt = _NP2DT.get(disp.dtype)
@@ -344,8 +389,16 @@ class Context:
         h, w = disp.shape
         cfg = self.config()
         cap = roi_points(w, h, cfg.border) if capacity is None else capacity
-        out = np.empty((max(cap, 1), 4), dtype=np.float32)
-        idx = np.empty(max(cap, 1), dtype=np.uint32) if want_index else None
+        if out is None:
+            out = np.empty((max(cap, 1), 4), dtype=np.float32)
+        else:
+            assert out.dtype == np.float32 and out.flags.c_contiguous and out.size >= 4 * cap
+            want_index = want_index or out_index is not None
+        if want_index and out_index is not None:
+            assert out_index.dtype == np.uint32 and out_index.flags.c_contiguous and out_index.size >= cap
+            idx = out_index
+        else:
+            idx = np.empty(max(cap, 1), dtype=np.uint32) if want_index else None
         n = ctypes.c_size_t(0)
         st = self._L.d2pc_process(self._h, disp.ctypes.data, dt, scale, w, h, disp.strides[0], out.ctypes.data,
                                   idx.ctypes.data if want_index else None, cap, ctypes.byref(n))

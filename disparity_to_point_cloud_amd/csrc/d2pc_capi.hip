@@ -391,6 +391,25 @@ void classify_q(d2pc_ctx *ctx) {
   ctx->qs.b = q[15] + z;
 }
 
+// Device-visible address of `p` when it lies in pinned host memory whose mapping covers `bytes` (memory from
+// d2pc_host_alloc / hipHostMalloc / hipHostRegister), else nullptr.
+void *pinned_device_view(const void *p, size_t bytes) {
+  if (!p) return nullptr;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory: not an error here
+    return nullptr;
+  }
+  if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+  hipPointerAttribute_t end;
+  if (bytes > 1 && (hipPointerGetAttributes(&end, static_cast<const char *>(p) + bytes - 1) != hipSuccess ||
+                    end.type != hipMemoryTypeHost)) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return at.devicePointer;
+}
+
 // cpp:55-57 + cpp:69-72: the reference filters the whole image and then reads only the inset ROI ("Removing
 // borders" -- the inset exists to hide the filter's border artefacts).  The fused entry points therefore
 // compute the median of the ROI pixels only (25.5 % fewer at the native 752x480, border 40); the windows
@@ -445,12 +464,20 @@ int d2pc_device_count(void) {
 // hpp:84-104: cv::stereoRectify closed form for the reference rig (see
 // SURVEY.md section 8 row a9): f' = fy; c' = (n-1)/2 - f'((n-1)/2 - c)/f;
 // Q = [1 0 0 -cx'; 0 1 0 -cy'; 0 0 0 f'; 0 0 -1/Tx (cx1'-cx2')/Tx], Tx = -b.
-int d2pc_make_q(double fx, double fy, double cx, double cy, double baseline, int nx, int ny, double q[16]) {
+int d2pc_make_q_flavour(double fx, double fy, double cx, double cy, double baseline, int nx, int ny, int flavour,
+                        double q[16]) {
   if (!q || !(fx > 0) || !(fy > 0) || !(baseline != 0) || nx <= 0 || ny <= 0) return D2PC_ERR_INVALID_ARG;
   const double f = fy;
-  const double hx = double(nx - 1) / 2.0, hy = double(ny - 1) / 2.0;
-  const double cxn = hx - f * (hx - cx) / fx;
-  const double cyn = hy - f * (hy - cy) / fy;
+  double hx, hy, ox, oy;  // centre of the undistorted corners, and the centre the result is re-centred on
+  switch (flavour) {
+    case D2PC_STEREORECTIFY_CONTINUOUS: ox = hx = double(nx - 1) / 2.0; oy = hy = double(ny - 1) / 2.0; break;
+    case D2PC_STEREORECTIFY_CV24: hx = double(nx) / 2.0; hy = double(ny) / 2.0; ox = double(nx / 2); oy = double(ny / 2); break;
+    case D2PC_STEREORECTIFY_CV3:
+      hx = double(nx - 1) / 2.0; hy = double(ny - 1) / 2.0; ox = double((nx - 1) / 2); oy = double((ny - 1) / 2); break;
+    default: return D2PC_ERR_INVALID_ARG;
+  }
+  const double cxn = ox - f * (hx - cx) / fx;
+  const double cyn = oy - f * (hy - cy) / fy;
   const double tx = -baseline;
   for (int i = 0; i < 16; ++i) q[i] = 0.0;
   q[0] = 1.0;  q[3] = -cxn;
@@ -461,6 +488,10 @@ int d2pc_make_q(double fx, double fy, double cx, double cy, double baseline, int
   return D2PC_OK;
 }
 
+int d2pc_make_q(double fx, double fy, double cx, double cy, double baseline, int nx, int ny, double q[16]) {
+  return d2pc_make_q_flavour(fx, fy, cx, cy, baseline, nx, ny, D2PC_STEREORECTIFY_CONTINUOUS, q);
+}
+
 int d2pc_make_q_disparity_image(double f, double T, double cx, double cy, double q[16]) {
   if (!q || !(f > 0) || !(T > 0) || !std::isfinite(cx) || !std::isfinite(cy)) return D2PC_ERR_INVALID_ARG;
   for (int i = 0; i < 16; ++i) q[i] = 0.0;
@@ -469,6 +500,19 @@ int d2pc_make_q_disparity_image(double f, double T, double cx, double cy, double
   q[11] = f;
   q[14] = 1.0 / T;
   return D2PC_OK;
+}
+
+void *d2pc_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void d2pc_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int d2pc_config_init(d2pc_config *cfg) {
@@ -809,8 +853,15 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
   if ((st = grow(ctx, &ctx->d_in, &ctx->in_cap, pitch * size_t(height))) != D2PC_OK) return st;
   if (bridge16 && (st = grow(ctx, &ctx->d_cvt, &ctx->cvt_cap, kpitch * size_t(height))) != D2PC_OK) return st;
   if (median && (st = grow(ctx, &ctx->d_med, &ctx->med_cap, kpitch * size_t(height))) != D2PC_OK) return st;
-  if ((st = grow(ctx, &ctx->d_out, &ctx->out_cap, size_t(g.roi_n) * 16)) != D2PC_OK) return st;
-  if (out_index && (st = grow(ctx, &ctx->d_idx, &ctx->idx_cap, size_t(g.roi_n) * 4)) != D2PC_OK) return st;
+  // pinned output that holds the whole ROI: the kernels store the final bytes straight into it
+  void *direct_out = capacity >= g.roi_n && reinterpret_cast<uintptr_t>(out_points) % 16 == 0
+                         ? pinned_device_view(out_points, size_t(g.roi_n) * 16) : nullptr;
+  void *direct_idx = direct_out && out_index ? pinned_device_view(out_index, size_t(g.roi_n) * 4) : nullptr;
+  if (out_index && !direct_idx) direct_out = nullptr;  // both or neither
+  if (!direct_out) {
+    if ((st = grow(ctx, &ctx->d_out, &ctx->out_cap, size_t(g.roi_n) * 16)) != D2PC_OK) return st;
+    if (out_index && (st = grow(ctx, &ctx->d_idx, &ctx->idx_cap, size_t(g.roi_n) * 4)) != D2PC_OK) return st;
+  }
   hipStream_t s = ctx->stream;
   SyncOnExit drain(s);
   const bool timing = ctx->stage_timing != 0;
@@ -840,8 +891,9 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
     kernel_in = ctx->d_med;
   }
   D2PC_HIP(ctx, mark(2));
-  uint32_t *kidx = out_index ? static_cast<uint32_t *>(ctx->d_idx) : nullptr;
-  st = enqueue(ctx, g, kernel_in, kdtype, ctx->d_out, kidx, ctx->d_counts, s);
+  void *kout = direct_out ? direct_out : ctx->d_out;
+  uint32_t *kidx = !out_index ? nullptr : static_cast<uint32_t *>(direct_out ? direct_idx : ctx->d_idx);
+  st = enqueue(ctx, g, kernel_in, kdtype, kout, kidx, ctx->d_counts, s);
   if (st != D2PC_OK) return st;
   D2PC_HIP(ctx, mark(3));
   size_t n = g.roi_n;
@@ -851,7 +903,7 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
     if (ctx->h_counts[0] == kCountTimedOut) {
       // the single pass gave up waiting for a predecessor (only ever selected here by cfg.compact_algo = 2):
       // this entry point is synchronous, so run the frame again with the two-pass form, which cannot wait
-      st = enqueue(ctx, g, kernel_in, kdtype, ctx->d_out, kidx, ctx->d_counts, s, nullptr, 1);
+      st = enqueue(ctx, g, kernel_in, kdtype, kout, kidx, ctx->d_counts, s, nullptr, 1);
       if (st != D2PC_OK) return st;
       D2PC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       D2PC_HIP(ctx, hipStreamSynchronize(s));
@@ -860,7 +912,7 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
     if (n > g.roi_n) return fail(ctx, D2PC_ERR_INTERNAL, "compaction reported %zu points for %u ROI pixels", n, g.roi_n);
     if (n > capacity) return fail(ctx, D2PC_ERR_CAPACITY, "capacity %zu < %zu valid points", capacity, n);
   }
-  if (n) {
+  if (n && !direct_out) {
     D2PC_HIP(ctx, hipMemcpyAsync(out_points, ctx->d_out, n * 16, hipMemcpyDeviceToHost, s));
     if (out_index) D2PC_HIP(ctx, hipMemcpyAsync(out_index, ctx->d_idx, n * 4, hipMemcpyDeviceToHost, s));
   }

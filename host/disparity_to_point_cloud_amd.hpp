@@ -36,6 +36,7 @@ template <class Msgs>
 class Disparity2PCloudT {
  public:
   typedef typename Msgs::Image Image;
+  typedef typename Msgs::DisparityImage DisparityImage;
   typedef typename Msgs::PointCloud2 PointCloud2;
   typedef typename Msgs::PointField PointField;
   typedef std::function<void(const PointCloud2 &)> Publisher;  // p_cloud_pub_.publish
@@ -56,7 +57,9 @@ class Disparity2PCloudT {
  public:
   // hpp:75-106.  `q_from_opencv`: the ROS adaptor passes the Q_ that
   // cv::stereoRectify produced (hpp:104); without it the closed form of that
-  // call for this rig is used (d2pc_make_q).
+  // call for this rig is used, in the convention of the OpenCV the reference's
+  // era built against (2.4.x, ROS Indigo: d2pc_make_q_flavour CV24 -- for the
+  // defaults cx' = 376 exactly; see include/d2pc.h for the other conventions).
   Disparity2PCloudT(const ParamSource &nh, Publisher pub, int device_id = 0, const double *q_from_opencv = nullptr,
                     int mode = D2PC_MODE_PARITY, bool verbose = false, bool gpu_median = true)
       : p_cloud_pub_(std::move(pub)), verbose_(verbose), gpu_median_(gpu_median) {
@@ -68,7 +71,8 @@ class Disparity2PCloudT {
     nh.param("base_line_", base_line_, 0.09);
     if (q_from_opencv) {
       for (int i = 0; i < 16; ++i) Q_[i] = q_from_opencv[i];
-    } else if (d2pc_make_q(fx_, fy_, cx_, cy_, base_line_, 752, 480, Q_) != D2PC_OK) {  // hpp:101-104
+    } else if (d2pc_make_q_flavour(fx_, fy_, cx_, cy_, base_line_, 752, 480, D2PC_STEREORECTIFY_CV24, Q_) !=
+               D2PC_OK) {  // hpp:101-104
       throw std::runtime_error("bad calibration parameters");
     }
     if (verbose_) printf("stereoRectify\n");
@@ -130,6 +134,51 @@ class Disparity2PCloudT {
       printf("upload %.3f ms, median %.3f ms, reproject %.3f ms, download %.3f ms\n", tm.h2d_ms, tm.prep_ms,
              tm.kernel_ms, tm.d2h_ms);
 
+    finish_and_publish(output, n, msg->header.stamp);
+    if (verbose_) printf("publish\n");
+  }
+
+  // The TODO at hpp:65 ("get calibration from the camera"): a stereo_msgs/DisparityImage carries the disparities
+  // as 32FC1 together with f, T and min_disparity.  Same callback body from cpp:63 on -- Q from the MESSAGE
+  // (d2pc_make_q_disparity_image; the principal point stays ~cx_ / ~cy_, a DisparityImage has none), no
+  // mono8 decode, no median and no 1/8 scale: the image already holds final disparities, so it enters at
+  // the fp32 seam.  In COMPACT mode points with d <= min_disparity are dropped (stereo_image_proc's rule).
+  void DisparityImageCb(const typename DisparityImage::ConstPtr &msg) {
+    const Image &im = msg->image;
+    if (im.encoding != "32FC1") throw std::runtime_error("DisparityImage.image must be 32FC1, got [" + im.encoding + "]");
+    if (im.is_bigendian) throw std::runtime_error("big-endian 32FC1 images are not supported");
+    if (im.step < 4 * im.width || im.data.size() < size_t(im.step) * im.height)
+      throw std::runtime_error("image data smaller than step*height");
+    double q[16];
+    if (d2pc_make_q_disparity_image(double(msg->f), double(msg->T), cx_, cy_, q) != D2PC_OK)
+      throw std::runtime_error("DisparityImage: f and T must be positive");
+    bool same = true;
+    for (int i = 0; i < 16; ++i) same = same && q[i] == Q_[i];
+    if (!same) {  // recalibration: cameras rarely change f or T between frames
+      for (int i = 0; i < 16; ++i) Q_[i] = q[i];
+      check(d2pc_set_q(ctx_, Q_), "d2pc_set_q");
+    }
+    check(d2pc_set_min_disparity(ctx_, msg->min_disparity), "d2pc_set_min_disparity");
+    PointCloud2 output;
+    const size_t cap = d2pc_roi_points(int(im.width), int(im.height), 40);
+    output.data.resize(cap * 16);
+    size_t n = 0;
+    check(d2pc_process(ctx_, im.data.data(), D2PC_DTYPE_F32, 1.0f, int(im.width), int(im.height), size_t(im.step),
+                       output.data.data(), nullptr, cap, &n),
+          "d2pc_process");
+    output.data.resize(n * 16);
+    finish_and_publish(output, n, msg->header.stamp);
+  }
+
+ private:
+  void check(int st, const char *what) {
+    if (st != D2PC_OK)
+      throw std::runtime_error(std::string(what) + ": " + d2pc_status_string(st) + ": " + d2pc_last_error(ctx_));
+  }
+
+  // cpp:79-90
+  template <class Stamp>
+  void finish_and_publish(PointCloud2 &output, size_t n, const Stamp &stamp) {
     // cpp:79-85: width = N, height = 1, is_dense = false, field table
     d2pc_cloud_meta m;
     d2pc_cloud_meta_fill(ctx_, n, &m);
@@ -147,10 +196,9 @@ class Disparity2PCloudT {
       output.fields[i].count = m.fields[i].count;
     }
     // cpp:87-90
-    output.header.stamp = msg->header.stamp;
+    output.header.stamp = stamp;
     output.header.frame_id = "/camera_optical_frame";
     p_cloud_pub_(output);
-    if (verbose_) printf("publish\n");
   }
 };
 

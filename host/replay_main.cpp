@@ -4,7 +4,14 @@
 //   d2pc_replay cloud <in.raw> <w> <h> <mono8|mono16> <out.bin> [compact] [hostmedian] [step=N] [bigendian] [name=value ...]
 //        name=value sets a private parameter (~fx_ ~fy_ ~cx_ ~cy_ ~base_line_), as a launch file would
 //        full callback; writes PointCloud2 metadata (text) then the payload
+//        extra flags: pinned  = publish sensor_msgs::PointCloud2_<PinnedAllocator> (kernels store into output.data)
+//   d2pc_replay dispimage <in.f32> <w> <h> 32FC1 <out.bin> f=<px> T=<m> min_disparity=<d> [compact] [pinned] [step=N]
+//        the stereo_msgs/DisparityImage callback (hpp:65 TODO): calibration from the message
+//   d2pc_replay latency <in.raw> <w> <h> <mono8|mono16> <frames> [compact] [pinned]
+//        per-frame wall time of DisparityCb over <frames> calls (median, p10, p90 in microseconds)
 // <in.raw> holds the sensor_msgs/Image data bytes (row-major, step = w*bpp).
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +34,60 @@ static bool has_flag(int argc, char **argv, const char *flag) {
   return false;
 }
 
+template <class Cloud>
+static void write_cloud(const char *path, const Cloud &got) {
+  std::ofstream o(path, std::ios::binary);
+  o << "height " << got.height << " width " << got.width << " point_step " << got.point_step << " row_step "
+    << got.row_step << " is_bigendian " << got.is_bigendian << " is_dense " << got.is_dense << " frame_id "
+    << got.header.frame_id << " stamp " << got.header.stamp.sec << "." << got.header.stamp.nsec << " fields";
+  for (auto &f : got.fields) o << " " << f.name << ":" << f.offset << ":" << int(f.datatype) << ":" << f.count;
+  o << "\n";
+  o.write(reinterpret_cast<const char *>(got.data.data()), std::streamsize(got.data.size()));
+}
+
+static d2pc::ParamSource params_from(int argc, char **argv) {
+  d2pc::ParamSource nh;  // d2pcloud.launch sets no params: defaults apply
+  for (int i = 7; i < argc; ++i) {
+    const char *eq = strchr(argv[i], '=');
+    if (eq && strncmp(argv[i], "step=", 5)) nh.values[std::string(argv[i], size_t(eq - argv[i]))] = atof(eq + 1);
+  }
+  return nh;
+}
+
+// One callback through a node instantiated with the message policy M; returns the published cloud.
+template <class M, class Fn>
+static int run_node(int argc, char **argv, const char *out_path, Fn call) {
+  typename M::PointCloud2 got;
+  int published = 0;
+  d2pc::Disparity2PCloudT<M> node(
+      params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { got = pc; ++published; }, 0, nullptr,
+      has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false, !has_flag(argc, argv, "hostmedian"));
+  call(node);
+  if (published != 1) { fprintf(stderr, "nothing published\n"); return 3; }
+  write_cloud(out_path, got);
+  return 0;
+}
+
+template <class M>
+static int run_latency(int argc, char **argv, const std::shared_ptr<d2pc_shim::Image> &img, int frames) {
+  size_t last = 0;
+  d2pc::Disparity2PCloudT<M> node(
+      params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { last = pc.data.size(); }, 0, nullptr,
+      has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false, true);
+  for (int i = 0; i < 20; ++i) node.DisparityCb(img);
+  std::vector<double> us;
+  for (int i = 0; i < frames; ++i) {
+    const auto t0 = std::chrono::steady_clock::now();
+    node.DisparityCb(img);
+    us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+  std::sort(us.begin(), us.end());
+  printf("DisparityCb %ux%u %s %s payload: median %.1f us  p10 %.1f  p90 %.1f  (%zu bytes published)\n", img->width,
+         img->height, img->encoding.c_str(), has_flag(argc, argv, "pinned") ? "pinned  " : "pageable", us[us.size() / 2],
+         us[us.size() / 10], us[us.size() * 9 / 10], last);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 7) { fprintf(stderr, "usage: see replay_main.cpp\n"); return 2; }
   const std::string cmd = argv[1], enc = argv[5];
@@ -34,7 +95,7 @@ int main(int argc, char **argv) {
   img->width = uint32_t(atoi(argv[3]));
   img->height = uint32_t(atoi(argv[4]));
   img->encoding = enc;
-  img->step = img->width * (enc == "mono16" ? 2u : 1u);
+  img->step = img->width * (enc == "mono16" ? 2u : enc == "32FC1" ? 4u : 1u);
   for (int i = 7; i < argc; ++i)  // step=<bytes>: padded rows; bigendian: byte-swapped 16-bit samples
     if (!strncmp(argv[i], "step=", 5)) img->step = uint32_t(atoi(argv[i] + 5));
   img->is_bigendian = has_flag(argc, argv, "bigendian") ? 1 : 0;
@@ -49,27 +110,29 @@ int main(int argc, char **argv) {
       return 0;
     }
     if (cmd == "cloud") {
-      d2pc_shim::PointCloud2 got;
-      int published = 0;
-      d2pc::ParamSource nh;  // d2pcloud.launch sets no params: defaults apply
+      auto call = [&](auto &node) { node.DisparityCb(img); };
+      return has_flag(argc, argv, "pinned") ? run_node<d2pc_shim::PinnedMsgs>(argc, argv, argv[6], call)
+                                            : run_node<d2pc_shim::Msgs>(argc, argv, argv[6], call);
+    }
+    if (cmd == "dispimage") {
+      auto dm = std::make_shared<d2pc_shim::DisparityImage>();
+      dm->header = img->header;
+      dm->image = *img;
+      dm->image.step = img->width * 4u;
       for (int i = 7; i < argc; ++i) {
-        const char *eq = strchr(argv[i], '=');
-        if (eq && strncmp(argv[i], "step=", 5)) nh.values[std::string(argv[i], size_t(eq - argv[i]))] = atof(eq + 1);
+        if (!strncmp(argv[i], "step=", 5)) dm->image.step = uint32_t(atoi(argv[i] + 5));
+        if (!strncmp(argv[i], "f=", 2)) dm->f = float(atof(argv[i] + 2));
+        if (!strncmp(argv[i], "T=", 2)) dm->T = float(atof(argv[i] + 2));
+        if (!strncmp(argv[i], "min_disparity=", 14)) dm->min_disparity = float(atof(argv[i] + 14));
       }
-      d2pc::Disparity2PCloudT<d2pc_shim::Msgs> node(
-          nh, [&](const d2pc_shim::PointCloud2 &pc) { got = pc; ++published; }, 0, nullptr,
-          has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false,
-          !has_flag(argc, argv, "hostmedian"));
-      node.DisparityCb(img);
-      if (published != 1) { fprintf(stderr, "nothing published\n"); return 3; }
-      std::ofstream o(argv[6], std::ios::binary);
-      o << "height " << got.height << " width " << got.width << " point_step " << got.point_step << " row_step "
-        << got.row_step << " is_bigendian " << got.is_bigendian << " is_dense " << got.is_dense << " frame_id "
-        << got.header.frame_id << " stamp " << got.header.stamp.sec << "." << got.header.stamp.nsec << " fields";
-      for (auto &f : got.fields) o << " " << f.name << ":" << f.offset << ":" << int(f.datatype) << ":" << f.count;
-      o << "\n";
-      o.write(reinterpret_cast<const char *>(got.data.data()), std::streamsize(got.data.size()));
-      return 0;
+      auto call = [&](auto &node) { node.DisparityImageCb(dm); };
+      return has_flag(argc, argv, "pinned") ? run_node<d2pc_shim::PinnedMsgs>(argc, argv, argv[6], call)
+                                            : run_node<d2pc_shim::Msgs>(argc, argv, argv[6], call);
+    }
+    if (cmd == "latency") {
+      const int frames = atoi(argv[6]);
+      return has_flag(argc, argv, "pinned") ? run_latency<d2pc_shim::PinnedMsgs>(argc, argv, img, frames)
+                                            : run_latency<d2pc_shim::Msgs>(argc, argv, img, frames);
     }
   } catch (const std::exception &e) {
     fprintf(stderr, "exception: %s\n", e.what());

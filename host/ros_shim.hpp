@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "image_prep.hpp"
+#include "pinned_allocator.hpp"
 
 namespace d2pc_shim {
 
@@ -43,24 +44,48 @@ struct PointField {  // sensor_msgs/PointField
   uint32_t count = 0;
 };
 
-struct PointCloud2 {  // sensor_msgs/PointCloud2
+template <class ByteAlloc>
+struct PointCloud2_ {  // sensor_msgs/PointCloud2_<ContainerAllocator>
   Header header;
   uint32_t height = 0, width = 0;
   std::vector<PointField> fields;
   bool is_bigendian = false;
   uint32_t point_step = 0, row_step = 0;
-  std::vector<uint8_t> data;
+  std::vector<uint8_t, ByteAlloc> data;
   bool is_dense = false;
 };
+typedef PointCloud2_<std::allocator<uint8_t>> PointCloud2;
+// the payload in page-locked memory the kernels store into directly (pinned_allocator.hpp)
+typedef PointCloud2_<d2pc::PinnedAllocator<uint8_t>> PinnedPointCloud2;
 
-struct Msgs {
+struct RegionOfInterest {  // sensor_msgs/RegionOfInterest
+  uint32_t x_offset = 0, y_offset = 0, height = 0, width = 0;
+  bool do_rectify = false;
+};
+
+struct DisparityImage {  // stereo_msgs/DisparityImage
+  Header header;
+  Image image;             // 32FC1 disparities
+  float f = 0.f;           // focal length, pixels
+  float T = 0.f;           // baseline, world units
+  RegionOfInterest valid_window;
+  float min_disparity = 0.f, max_disparity = 0.f;
+  float delta_d = 0.f;
+  typedef std::shared_ptr<const DisparityImage> ConstPtr;
+};
+
+template <class Cloud>
+struct MsgsT {
   typedef d2pc_shim::Image Image;
+  typedef d2pc_shim::DisparityImage DisparityImage;
   typedef d2pc_shim::PointField PointField;
-  typedef d2pc_shim::PointCloud2 PointCloud2;
+  typedef Cloud PointCloud2;
   // cpp:50 + cpp:55-57 without cv_bridge / OpenCV
   static d2pc::Mono8 prepare(const Image &msg, int median_ksize) {
     return d2pc::median_blur(d2pc::to_mono8(msg), median_ksize);
   }
 };
+typedef MsgsT<PointCloud2> Msgs;              // pageable payload, as the reference's message
+typedef MsgsT<PinnedPointCloud2> PinnedMsgs;  // zero-copy payload
 
 }  // namespace d2pc_shim

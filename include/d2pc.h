@@ -111,9 +111,33 @@ int d2pc_device_count(void);            /* number of HIP devices, 0 if none  */
 /* Closed form of the reference's cv::stereoRectify call for its rig
  * (identical pinhole cameras, zero distortion, R = I, t = (-baseline,0,0),
  * image size (nx,ny) = (752,480) at hpp:101-103).  Host-only helper for
- * ROS-free callers; the ROS adaptor passes OpenCV's own Q_ to d2pc_set_q. */
+ * ROS-free callers; the ROS adaptor passes OpenCV's own Q_ to d2pc_set_q.
+ * d2pc_make_q = D2PC_STEREORECTIFY_CONTINUOUS below. */
 int d2pc_make_q(double fx, double fy, double cx, double cy, double baseline,
                 int nx, int ny, double q_out[16]);
+
+/* Where stereoRectify puts the new principal point depends on the OpenCV
+ * release (the image-corner coordinates and the centre it re-centres on
+ * changed between 2.4 and 3.x), and the reference pins no version.  For the
+ * reference's case (no distortion, R = I) with c = source principal point,
+ * n = image extent, f' = fy:
+ *   CONTINUOUS  c' = (n-1)/2.0 - f'((n-1)/2.0 - c)/f   SURVEY.md section 8 row a9; no release computes
+ *               exactly this (real-valued centre), it is "this closed form"
+ *   CV24        c' = n/2 - f'(n/2.0 - c)/f     OpenCV 2.4.x (ROS Indigo, what .clang_complete:2 points at):
+ *               corners at 0 and n, integer n/2.  752x480 defaults: cx' = 376 exactly
+ *   CV3         c' = (n-1)/2 - f'((n-1)/2.0 - c)/f   OpenCV 3.x/4.x: corners at 0 and n-1, INTEGER (n-1)/2.
+ *               752x480 defaults: cx' = 375.4995...
+ * OpenCV evaluates parts of this in float, so none of the three is bit-for-bit
+ * a release's Q: a node that has OpenCV passes ITS Q to d2pc_set_q
+ * (ros/disparity_to_point_cloud_node.cpp does); the host mirror without OpenCV
+ * defaults to CV24. */
+typedef enum d2pc_stereorectify_flavour {
+  D2PC_STEREORECTIFY_CONTINUOUS = 0,
+  D2PC_STEREORECTIFY_CV24 = 1,
+  D2PC_STEREORECTIFY_CV3 = 2
+} d2pc_stereorectify_flavour;
+int d2pc_make_q_flavour(double fx, double fy, double cx, double cy, double baseline,
+                        int nx, int ny, int flavour, double q_out[16]);
 
 /* Q for a stereo_msgs/DisparityImage-style source (SURVEY.md section 8(f) #3:
  * calibration carried by the message instead of ~fx_.. parameters): focal
@@ -258,6 +282,21 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
                         size_t row_stride_bytes, int median_ksize, float scale,
                         void *out_points, uint32_t *out_index,
                         size_t capacity_points, size_t *n_points);
+
+/*
+ * Pinned (page-locked) host buffers for the synchronous entry points above
+ * ("write the output into a pinned buffer that IS
+ * output.data").  When `out_points` (and `out_index`, if given) of a
+ * d2pc_process* call lie in memory from d2pc_host_alloc and hold the whole ROI
+ * (capacity_points >= ROI points), the kernels store the final PointCloud2
+ * bytes straight into it over PCIe: no device-side copy of the cloud, no
+ * D2H copy, no bounce through the runtime's staging buffers.  A pinned `disp`
+ * / `image` makes the upload one DMA.  Pageable buffers keep working as before.
+ * host/pinned_allocator.hpp wraps these two in a caching std::allocator so that
+ * sensor_msgs::PointCloud2_<Alloc>::data can be such a buffer.
+ */
+void *d2pc_host_alloc(size_t bytes);
+void d2pc_host_free(void *p);
 
 /*
  * Pipelined host path: up to `depth`

@@ -1,6 +1,8 @@
 // ros/disparity_to_point_cloud_node.cpp -- the ROS node, source only (this
-// image has no ROS / OpenCV / cv_bridge, so it cannot be compiled here; it is
-// covered through the ROS-free instantiation in host/ and tests/).
+// image has no ROS / OpenCV / cv_bridge, so it cannot be built here; its logic is
+// covered through the ROS-free instantiation in host/ and tests/, and the file
+// itself is parsed and type-checked against declaration-only stubs by
+// tests/test_abi_cpu.py::test_ros_adaptor_parses -- a syntax check, nothing more).
 //
 // Same node name, topics, queue sizes, latching and private parameters as the
 // reference (src/disparity_to_point_cloud_node.cpp:46-52,
@@ -14,13 +16,19 @@
 #include <ros/ros.h>
 #include <sensor_msgs/Image.h>
 #include <sensor_msgs/PointCloud2.h>
+#include <stereo_msgs/DisparityImage.h>
 
 #include "../host/disparity_to_point_cloud_amd.hpp"
+#include "../host/pinned_allocator.hpp"
 
 struct RosMsgs {
   typedef sensor_msgs::Image Image;
-  typedef sensor_msgs::PointField PointField;
-  typedef sensor_msgs::PointCloud2 PointCloud2;
+  typedef stereo_msgs::DisparityImage DisparityImage;
+  // ROS 1 messages are templated on their container allocator: the cloud's byte vector lives in page-locked
+  // memory (small members fall through to malloc), and the kernels store the final bytes straight into it
+  typedef d2pc::PinnedAllocator<void> CloudAlloc;
+  typedef sensor_msgs::PointField_<CloudAlloc> PointField;
+  typedef sensor_msgs::PointCloud2_<CloudAlloc> PointCloud2;
   static d2pc::Mono8 prepare(const Image &msg, int median_ksize) {
     cv_bridge::CvImagePtr disparity = cv_bridge::toCvCopy(msg, "mono8");          // cpp:50
     cv::Mat median_filtered(disparity->image.size(), CV_8U);
@@ -54,13 +62,20 @@ int main(int argc, char *argv[]) {
   cv::stereoRectify(K, dist, K, dist, cv::Size(752, 480), R, t, R1, R2, P1, P2, Q);
   Q.convertTo(Q, CV_64F);
 
-  ros::Publisher pub = nh.advertise<sensor_msgs::PointCloud2>("/point_cloud", 1, true);  // hpp:80-81 (latched)
+  ros::Publisher pub = nh.advertise<RosMsgs::PointCloud2>("/point_cloud", 1, true);  // hpp:80-81 (latched)
   int device = 0;
   nh.param("device_id", device, 0);  // rank-local GPU when several nodes share a host
   d2pc::Disparity2PCloudT<RosMsgs> node(
-      params, [&](const sensor_msgs::PointCloud2 &pc) { pub.publish(pc); }, device, Q.ptr<double>());
+      params, [&](const RosMsgs::PointCloud2 &pc) { pub.publish(pc); }, device, Q.ptr<double>());
   ros::Subscriber sub = nh.subscribe<sensor_msgs::Image>(
       "/disparity", 1, [&](const sensor_msgs::ImageConstPtr &msg) { node.DisparityCb(msg); });  // hpp:77-78
+  // hpp:65 TODO ("get calibration from the camera"): a stereo_msgs/DisparityImage on an extra topic carries f, T
+  // and min_disparity with the 32FC1 disparities; an extra input topic that stays silent unless something
+  // publishes on it, so the reference's launch file is unaffected
+  ros::Subscriber sub_di = nh.subscribe<stereo_msgs::DisparityImage>(
+      "/disparity_image", 1, [&](const stereo_msgs::DisparityImageConstPtr &msg) { node.DisparityImageCb(msg); });
+  (void)sub;
+  (void)sub_di;
   ros::spin();  // single-threaded, as the reference (node.cpp:50)
   return 0;
 }

@@ -176,3 +176,33 @@ def test_public_header_is_plain_c99_and_cxx11(tmp_path):
         p = subprocess.run(cmd + ["-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o",
                                   str(tmp_path / "hdr.o")], capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
+
+
+def test_ros_adaptor_parses():
+    """SYNTAX CHECK ONLY: ros/disparity_to_point_cloud_node.cpp cannot be built here (no ROS, OpenCV, cv_bridge in
+    the image); it is parsed and type-checked against the declaration-only stubs under tests/stubs/ so that typos,
+    missing members and template errors in the adaptor are caught.  Nothing is linked or run, and the stubs pin no
+    behaviour of ROS, OpenCV or the reference."""
+    import subprocess
+
+    src = os.path.join(ROOT, "ros", "disparity_to_point_cloud_node.cpp")
+    p = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I",
+                        os.path.join(ROOT, "tests", "stubs"), src], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-3000:]
+
+
+def test_stereorectify_flavours():
+    """d2pc_make_q_flavour: where the new principal point lands depends on the OpenCV release; none of the
+    three conventions is claimed to be a release's Q bit for bit (OpenCV computes part of it in float)."""
+    d = dict(fx=714.24, fy=713.5, cx=376.0, cy=240.0, baseline=0.09, nx=752, ny=480)
+    cont = d2pc.make_q_flavour(flavour=d2pc.STEREORECTIFY_CONTINUOUS, **d)
+    cv24 = d2pc.make_q_flavour(flavour=d2pc.STEREORECTIFY_CV24, **d)
+    cv3 = d2pc.make_q_flavour(flavour=d2pc.STEREORECTIFY_CV3, **d)
+    assert cont.tobytes() == d2pc.make_q(**d).tobytes()             # d2pc_make_q is "this closed form"
+    assert abs(-cont[3] - 375.999481966846) < 1e-9                  # SURVEY.md row a9's constant: the CONTINUOUS form
+    assert -cv24[3] == 376.0 and -cv24[7] == 240.0                  # 2.4: corners 0..n, integer n/2
+    assert abs(-cv3[3] - (375.0 - 713.5 * (375.5 - 376.0) / 714.24)) < 1e-12 and abs(-cv3[3] - 375.4995) < 1e-4
+    for q in (cont, cv24, cv3):                                     # everything else is common
+        assert q[11] == 713.5 and abs(q[14] - 1 / 0.09) < 1e-12 and q[15] == 0.0 and np.signbit(q[15])
+    with pytest.raises(d2pc.D2pcError):
+        d2pc.make_q_flavour(flavour=7, **d)

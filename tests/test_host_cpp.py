@@ -87,7 +87,7 @@ def test_c1_full_callback_640x480_mono16(replay, tmp_path, mode, median):
     m = dict(zip(kv[0:16:2], kv[1:16:2]))
     pts = np.frombuffer(payload, dtype=np.float32).reshape(-1, 4)
     # the oracle pipeline: toCvCopy(mono8) -> medianBlur 11 -> x1/8 -> reproject + ROI pack
-    q = d2pc.make_q()
+    q = d2pc.make_q_flavour()  # the mirror without OpenCV: the 2.4 convention (cx' = 376 for the defaults)
     med = oracle.median_u8(oracle.mono16_to_mono8(img), 11)
     if mode == "parity":
         want = oracle.reproject(med, q, border=40, scale=0.125)
@@ -115,7 +115,7 @@ def test_private_parameters_reach_the_calibration(replay, tmp_path):
     assert p.returncode == 0, p.stderr
     payload = dst.read_bytes().split(b"\n", 1)[1]
     pts = np.frombuffer(payload, dtype=np.float32).reshape(-1, 4)
-    q = d2pc.make_q(nx=752, ny=480, **params)  # hpp:101-103: rectification size stays 752x480
+    q = d2pc.make_q_flavour(nx=752, ny=480, **params)  # hpp:101-103: rectification size stays 752x480
     want = oracle.reproject(oracle.median_u8(img, 11), q, border=40, scale=0.125)
     assert_points_close(pts, want, max_ulp=1, rel=1e-5, what="custom calibration")
 
@@ -150,4 +150,63 @@ def test_mono16_message_layouts(replay, tmp_path, variant):
     _, payload = dst.read_bytes().split(b"\n", 1)
     pts = np.frombuffer(payload, dtype=np.float32).reshape(-1, 4)
     med = oracle.median_u8(oracle.mono16_to_mono8(img), 11)
-    assert_points_close(pts, oracle.reproject(med, d2pc.make_q(), border=40, scale=0.125), max_ulp=1, what=variant)
+    assert_points_close(pts, oracle.reproject(med, d2pc.make_q_flavour(), border=40, scale=0.125), max_ulp=1, what=variant)
+
+
+def _cloud(dst):
+    meta, payload = dst.read_bytes().split(b"\n", 1)
+    kv = meta.decode().split()
+    return dict(zip(kv[0:16:2], kv[1:16:2])), np.frombuffer(payload, dtype=np.float32).reshape(-1, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("payload", ["pageable", "pinned"])
+@pytest.mark.parametrize("mode", ["parity", "compact"])
+def test_disparity_image_callback_takes_its_calibration_from_the_message(replay, tmp_path, mode, payload):
+    """hpp:65 TODO / SURVEY 8(f)#3: a stereo_msgs/DisparityImage (32FC1 + f, T, min_disparity) through
+    DisparityImageCb: Q from the message (principal point from ~cx_/~cy_), fp32 seam, no median, no 1/8."""
+    import disparity_to_point_cloud_amd as d2pc
+
+    rng = np.random.default_rng(77)
+    disp = rng.uniform(0.0, 64.0, size=(240, 400)).astype(np.float32)
+    disp[rng.random(disp.shape) < 0.2] = 0.0                 # no match
+    disp[50:60, 100:140] = np.float32(1.5)                   # below min_disparity
+    f, T, dmin = 412.5, 0.12, 2.0
+    extra = [f"f={f}", f"T={T}", f"min_disparity={dmin}", "cx_=201.5", "cy_=118.25"]
+    if mode == "compact":
+        extra.append("compact")
+    if payload == "pinned":
+        extra.append("pinned")
+    p, dst = _run(replay, "dispimage", disp, "32FC1", tmp_path, *extra)
+    assert p.returncode == 0, p.stderr
+    m, pts = _cloud(dst)
+    q = d2pc.make_q_disparity_image(np.float32(f), np.float32(T), 201.5, 118.25)  # the message fields are float32
+    if mode == "parity":
+        want = oracle.reproject(disp, q, border=40)
+    else:
+        want, _ = oracle.reproject_compact(disp, q, border=40, min_disparity=dmin)
+        assert len(want) < (400 - 80) * (240 - 80) * 0.85     # holes and sub-threshold pixels really dropped
+    assert_points_close(pts, want, max_ulp=1, rel=1e-5, what="DisparityImage callback")
+    assert m["width"] == str(len(want)) and m["is_dense"] == ("1" if mode == "compact" else "0")
+    assert m["frame_id"] == "/camera_optical_frame" and m["stamp"] == "1234.5678"
+
+
+@pytest.mark.gpu
+def test_disparity_image_callback_rejects_other_encodings(replay, tmp_path):
+    img = np.zeros((100, 100), dtype=np.uint8)
+    p, _ = _run(replay, "dispimage", img, "mono8", tmp_path, "f=400", "T=0.1")
+    assert p.returncode == 4 and "32FC1" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["parity", "compact"])
+def test_pinned_payload_is_byte_identical_to_the_pageable_one(replay, tmp_path, mode):
+    """sensor_msgs::PointCloud2_<PinnedAllocator>: the kernels store into output.data itself.  Same bytes."""
+    img = synth_disparity(1, 3, 752, 480, "mono16")
+    extra = ("compact",) if mode == "compact" else ()
+    p1, d1 = _run(replay, "cloud", img, "mono16", tmp_path, *extra)
+    assert p1.returncode == 0, p1.stderr
+    a = d1.read_bytes()
+    p2, d2 = _run(replay, "cloud", img, "mono16", tmp_path, "pinned", *extra)
+    assert p2.returncode == 0, p2.stderr
+    assert d2.read_bytes() == a

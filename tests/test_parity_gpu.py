@@ -375,3 +375,33 @@ def test_stage_timing_of_the_host_entry_points(q_default):
         assert t["total_ms"] < 100.0
         ctx.process(img.astype(np.float32))             # no median: prep stage is (nearly) empty
         assert ctx.last_stage_times()["prep_ms"] < t["prep_ms"]
+
+
+# ------------------------------------------------- pinned caller buffers (d2pc_host_alloc)
+@pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
+def test_pinned_output_is_written_directly_and_matches_the_staged_path(q_default, mode):
+    """out_points / out_index in memory from d2pc_host_alloc: the kernels store the final bytes there (no
+    device-side copy of the cloud, no D2H copy).  Bit-identical to the pageable path, nothing written past n."""
+    disp = synth_disparity(2, 9, 752, 480, "holes")
+    cap = d2pc.roi_points(752, 480, 40)
+    pts_buf, idx_buf = d2pc.PinnedBuffer((cap + 8, 4), np.float32), d2pc.PinnedBuffer(cap + 8, np.uint32)
+    pts_buf.array[:] = np.float32(-7.0)
+    idx_buf.array[:] = 0xDEADBEEF
+    with ctx_for(q_default, mode=mode) as ctx:
+        want_p, want_i = ctx.process(disp, want_index=True)
+        got_p, got_i = ctx.process(disp, out=pts_buf.array, out_index=idx_buf.array)
+        n = len(got_p)
+        assert n == len(want_p)
+        assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32)) and np.array_equal(got_i, want_i)
+        # the same memory the caller handed in, and untouched behind the points that were produced
+        assert got_p.ctypes.data == pts_buf.array.ctypes.data
+        if mode == d2pc.MODE_PARITY:
+            assert np.all(pts_buf.array[n:] == np.float32(-7.0)) and np.all(idx_buf.array[n:] == 0xDEADBEEF)
+        # a pinned buffer too small for the whole ROI (legal in COMPACT): the staged path takes over
+        if mode == d2pc.MODE_COMPACT:
+            small = d2pc.PinnedBuffer((n + 1, 4), np.float32)
+            again = ctx.process(disp, capacity=n + 1, out=small.array)
+            assert np.array_equal(again.view(np.uint32), want_p.view(np.uint32))
+            small.close()
+    pts_buf.close()
+    idx_buf.close()

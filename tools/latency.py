@@ -15,7 +15,9 @@ for (w, h) in ((752, 480), (640, 480), (1920, 1080)):
     for mode in (d2pc.MODE_PARITY, d2pc.MODE_COMPACT):
         with d2pc.Context(q=q, mode=mode) as ctx:
             cap = d2pc.roi_points(w, h, 40)
-            out = np.empty((cap, 4), dtype=np.float32)
+            pinned = len(sys.argv) > 1 and sys.argv[1] == "pinned"  # output buffer from d2pc_host_alloc
+            keep = d2pc.PinnedBuffer((cap, 4), np.float32) if pinned else None
+            out = keep.array if pinned else np.empty((cap, 4), dtype=np.float32)
             n = ctypes.c_size_t()
             def mono8(k):
                 assert L.d2pc_process_mono8(ctx.handle, img.ctypes.data, w, h, w, k, 0.125, out.ctypes.data, None, cap, ctypes.byref(n)) == 0
@@ -27,4 +29,4 @@ for (w, h) in ((752, 480), (640, 480), (1920, 1080)):
                 for _ in range(200):
                     t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
                 ts = np.array(ts) * 1e6
-                print(f"{w}x{h} {'parity ' if mode == 0 else 'compact'} {name:24s}: median {np.median(ts):7.1f} us  p10 {np.percentile(ts,10):7.1f}  p90 {np.percentile(ts,90):7.1f}  ({n.value} points)", flush=True)
+                print(f"{w}x{h} {'pinned  ' if pinned else 'pageable'} {'parity ' if mode == 0 else 'compact'} {name:24s}: median {np.median(ts):7.1f} us  p10 {np.percentile(ts,10):7.1f}  p90 {np.percentile(ts,90):7.1f}  ({n.value} points)", flush=True)
