@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "d2pc_pipeline_release", "d2pc_fuse_desc_init", "d2pc_fuse_device", "d2pc_crop_to_square",
     "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16", "d2pc_last_stage_times",
     "d2pc_median_roi_device", "d2pc_host_alloc", "d2pc_host_free", "d2pc_make_q_flavour",
+    "d2pc_process_mono_device",
 ]
 # d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
 (FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
@@ -179,6 +180,9 @@ def load_library():
     L.d2pc_mono16_to_mono8_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
                                               ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
     L.d2pc_last_stage_times.argtypes = [vp, ctypes.POINTER(StageTimes)]
+    L.d2pc_process_mono_device.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+                                           ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp,
+                                           ctypes.c_size_t, vp, vp]
     L.d2pc_host_alloc.argtypes = [ctypes.c_size_t]
     L.d2pc_host_alloc.restype = ctypes.c_void_p
     L.d2pc_host_free.argtypes = [vp]
@@ -460,6 +464,14 @@ class Context:
         self._check(self._L.d2pc_median_roi_device(self._h, d_src_ptr, width, height, src_row_stride,
                                                    src_frame_stride, n_frames, d_dst_ptr, dst_row_stride,
                                                    dst_frame_stride, ksize, stream_ptr))
+
+    def process_mono_device(self, d_image_ptr, dtype, width, height, row_stride, frame_stride, n_frames, median_ksize,
+                            scale, d_out_ptr, d_index_ptr, out_frame_stride_points, d_counts_ptr, stream_ptr=None):
+        """d2pc_process_mono_device: (rescale ->) median(ROI) -> reproject for a device-resident batch, the
+        filter and the reprojection overlapped on CU-partitioned streams."""
+        self._check(self._L.d2pc_process_mono_device(self._h, d_image_ptr, dtype, width, height, row_stride,
+                                                     frame_stride, n_frames, median_ksize, scale, d_out_ptr,
+                                                     d_index_ptr, out_frame_stride_points, d_counts_ptr, stream_ptr))
 
     def fuse_device(self, desc: "FuseDesc", stream_ptr=None):
         """d2pc_fuse_device: fusion rule + combined confidence + 3x3 median + crop on device planes."""

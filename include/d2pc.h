@@ -284,6 +284,33 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
                         size_t capacity_points, size_t *n_points);
 
 /*
+ * The whole callback body (cpp:50-85) for a BATCH of frames resident in HBM:
+ * [MONO16: cv_bridge rescale ->] k x k median over the inset ROI -> x scale ->
+ * reproject + pack, asynchronous on `stream` like d2pc_process_device (same
+ * output arguments).  dtype is D2PC_DTYPE_U8 or D2PC_DTYPE_MONO16;
+ * median_ksize 0/1 skips the filter.
+ *
+ * The median is VALU-bound and the reprojection HBM-bound, which invites
+ * overlapping them.  The tuning key "callback_chunks" (default 1 = off) cuts a
+ * big batch into that many chunks and filters chunk c+1 on one internal stream
+ * while chunk c is reprojected on another.  It is OFF by default because it
+ * did not pay on MI355X / ROCm 7.2 (profiles/r02_callback_overlap.txt): the
+ * two kernels running freely side by side finish only 8 % (shared CUs) to
+ * 15 % (disjoint CU sets) sooner than back to back -- the reprojection's own
+ * arithmetic competes with the filter for the same VALUs -- and every
+ * cross-stream dependency of a real pipeline costs ~20 us, so 2 chunks of
+ * 16 x 4K ranged from +8 % to -10 % between devices and finer chunks were
+ * always slower than no overlap.  Results never depend on the setting.
+ * The filtered frames live in context-owned scratch (grown on demand, so the
+ * first call of a size is not capturable; under stream capture the call runs
+ * in order on `stream`).
+ */
+int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int dtype, int width, int height,
+                             size_t row_stride_bytes, size_t frame_stride_bytes, int n_frames,
+                             int median_ksize, float scale, void *d_out_points, uint32_t *d_out_index,
+                             size_t out_frame_stride_points, uint32_t *d_counts, void *stream);
+
+/*
  * Pinned (page-locked) host buffers for the synchronous entry points above
  * ("write the output into a pinned buffer that IS
  * output.data").  When `out_points` (and `out_index`, if given) of a
@@ -423,7 +450,8 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * 4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by the tile count; 1..4096),
  * "onepass_blocks_per_cu", "force_general_q", "no_vec_rows", "fuse_rows" (rows per wave of
  * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
- * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits). */
+ * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
+ * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

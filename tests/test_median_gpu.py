@@ -185,3 +185,76 @@ def test_callback_body_is_graph_capturable():
         want = oracle.reproject(oracle.median_u8(oracle.mono16_to_mono8(np.roll(imgs, 1, axis=0)[f]), 11), q, border=40,
                                 scale=0.125)
         assert_points_close(res[f][0], want, max_ulp=1, what=f"graph replay, frame {f}")
+
+
+@pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
+@pytest.mark.parametrize("dtype", ["u8", "mono16"])
+@pytest.mark.parametrize("chunks", [2, 0, 4])
+def test_process_mono_device_is_the_callback_body_for_a_batch(mode, dtype, chunks):
+    """d2pc_process_mono_device: (rescale ->) median 11 over the ROI -> x 1/8 -> reproject for a device-resident
+    batch, cut into `callback_chunks` chunks pipelined over two internal streams (<= 1: everything in order on
+    the caller's stream).  The split must never show in the result."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    q = d2pc.make_q()
+    rng = np.random.default_rng(mode * 10 + chunks)
+    n, h, w = 7, 2000, 2448   # 34 Mpixel: big enough for the overlapped path to be taken
+    if dtype == "u8":
+        imgs = rng.integers(0, 256, size=(n, h, w)).astype(np.uint8)
+        src = torch.from_numpy(imgs).cuda()
+        m8, dt, rs = imgs, d2pc.DTYPE_U8, w
+    else:
+        imgs = rng.integers(0, 65536, size=(n, h, w)).astype(np.uint16)
+        src = torch.from_numpy(imgs.view(np.int16)).cuda()
+        m8, dt, rs = np.stack([oracle.mono16_to_mono8(i) for i in imgs]), d2pc.DTYPE_MONO16, 2 * w
+    with d2pc.Context(q=q, mode=mode) as ctx:
+        ctx.set_tuning("callback_chunks", chunks)           # 7 frames: chunks of 4+3 / 2+2+2+1
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        for _ in range(3):  # relaunch: streams, events and scratch are reused
+            with torch.cuda.stream(side):
+                b.points.fill_(0)   # on the caller's stream: the call must order itself behind it
+                ctx.process_mono_device(src.data_ptr(), dt, w, h, rs, rs * h, n, 11, 0.125, b.points.data_ptr(),
+                                        b.index.data_ptr(), b.stride, b.counts.data_ptr(), side.cuda_stream)
+            side.synchronize()   # the caller's stream alone: the internal streams must have joined it
+        res = b.results()
+        ctx.check_async_error()
+    for f in range(n):
+        filt = oracle.median_u8(m8[f], 11)
+        pts, idx = res[f]
+        if mode == d2pc.MODE_PARITY:
+            want = oracle.reproject(filt, q, border=40, scale=0.125)
+            assert len(pts) == len(want)
+        else:
+            want, wi = oracle.reproject_compact(filt, q, border=40, scale=0.125)
+            assert np.array_equal(idx, wi)
+        assert_points_close(pts, want, max_ulp=1, rel=1e-5, what=f"frame {f}")
+
+
+def test_process_mono_device_rejects_bad_arguments_and_runs_in_order_under_capture():
+    q = d2pc.make_q()
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, size=(4, 200, 320)).astype(np.uint8)
+    n, h, w = imgs.shape
+    src = torch.from_numpy(imgs).cuda()
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    with d2pc.Context(q=q) as ctx:
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8)
+        args = (w, h, w, w * h, n, 11, 0.125, b.points.data_ptr(), None, b.stride, b.counts.data_ptr())
+        with pytest.raises(d2pc.D2pcError):
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_F32, *args)
+        with pytest.raises(d2pc.D2pcError):
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 4, 0.125, b.points.data_ptr(), None,
+                                    b.stride, b.counts.data_ptr())
+        s = torch.cuda.current_stream().cuda_stream
+        ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, *args, s)   # allocates the scratch
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):   # CU masks are a stream property a graph does not keep: in order on the capture stream
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, *args, torch.cuda.current_stream().cuda_stream)
+        b.points.fill_(0)
+        g.replay()
+        res = b.results()
+    for f in range(n):
+        want = oracle.reproject(oracle.median_u8(imgs[f], 11), q, border=40, scale=0.125)
+        assert_points_close(res[f][0], want, max_ulp=1, what=f"captured frame {f}")

@@ -23,6 +23,7 @@ def t(fn, iters=10, rounds=5):
     return float(np.median(ts))
 
 q = d2pc.make_q()
+torch.cuda.set_stream(torch.cuda.Stream())  # not the legacy default stream (it synchronises with every blocking stream)
 s = torch.cuda.current_stream().cuda_stream
 for (w, h, n) in ((752, 480, 64), (1920, 1080, 16), (3840, 2160, 16)):
     ctx = d2pc.Context(q=q)
@@ -39,5 +40,11 @@ for (w, h, n) in ((752, 480, 64), (1920, 1080, 16), (3840, 2160, 16)):
         b.launch(scale=0.125)
     us = t(body)
     us_r = t(lambda: b.launch(scale=0.125))
+    for chunks in (1, 2, 4):
+        ctx.set_tuning("callback_chunks", chunks)
+        uf = t(lambda: ctx.process_mono_device(raw.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125,
+                                               b.points.data_ptr(), None, b.stride, b.counts.data_ptr(), s))
+        print(f"{w}x{h} x{n}: d2pc_process_mono_device callback_chunks={chunks}: {uf:8.1f} us = "
+              f"{n*w*h/uf:9.1f} Mpix/s  ({us/uf:.3f}x the two launches in order)", flush=True)
     print(f"{w}x{h} x{n}: callback body (ROI median11 + reproject u8) {us:8.1f} us = {us/n:7.2f} us/frame {n*w*h/us:9.1f} Mpix/s; reproject alone {us_r:8.1f} us", flush=True)
     ctx.close()

@@ -9,6 +9,7 @@ OUT=gpurun_out/pmc_${TAG}
 mkdir -p $OUT
 run() {  # name, counters...
   local name=$1; shift
+  if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $name "; then return; fi   # PASSES="sq1 sq2": a subset
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o run -- python3 tools/probe.py --workload $WL --launches $N > $OUT/$name.log 2>&1
   echo "pass $name done"
 }

@@ -21,6 +21,7 @@ WORKLOADS = {  # name: (mode, frames, W, H, border, hole fraction, blocky, indic
     "compact_blocky_idx": ("compact", 16, 3840, 2160, 40, 0.3, 1, True, "f32"),
     "compact_1080p_x32":  ("compact", 32, 1920, 1080, 40, 0.3, 0, True, "f32"),
     "compact_1080p_x1":   ("compact", 1, 1920, 1080, 40, 0.3, 0, True, "f32"),
+    "median11_roi":       ("median", 16, 3840, 2160, 40, 0.0, 0, False, "u8"),
 }
 
 
@@ -51,6 +52,24 @@ def main():
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--scale", type=float, default=None)
     a = ap.parse_args()
+    if WORKLOADS[a.workload][0] == "median":   # k_median_u8<11> over the inset ROI, 16 x 4K (cpp:55-57)
+        _, F, W, H, border, *_ = WORKLOADS[a.workload]
+        ctx = d2pc.Context(q=d2pc.make_q(), border=border)
+        raw = torch.randint(0, 256, (F, H, W), dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(raw)
+        s = torch.cuda.current_stream().cuda_stream
+        run = lambda: ctx.median_roi_device(raw.data_ptr(), W, H, W, W * H, F, dst.data_ptr(), W, W * H, 11, s)
+        run(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.launches):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.launches
+        px = F * (W - 2 * border) * (H - 2 * border)
+        print(json.dumps({"workload": a.workload, "launches": a.launches, "ms_per_launch": round(ms, 4), "points": px,
+                          "roi_pixels": px, "algorithmic_bytes": 2 * px, "algorithmic_GBs": round(2 * px / ms / 1e6, 1)}))
+        return
     ctx, b = make_batch(a.workload, a.algo)
     scale = a.scale if a.scale is not None else (0.125 if b.disp.dtype == torch.uint8 else 1.0)
     b.launch(scale=scale)
