@@ -107,6 +107,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 W4K, H4K = 3840, 2160
 
 
+def build_id():
+    """sha256/12 of the kernel + ABI sources the loaded libd2pc.so was built from (tracked profiles carry the
+    same id, so a stale profile is visible in the bench line)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "disparity_to_point_cloud_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def fill_batch(batch, rank, kind):
     """Ring of distinct seeded frames (config 4), different per rank."""
     for f in range(batch.n_frames):
@@ -347,13 +359,18 @@ def main():
     }
     if a.share_gpu:
         out["config"]["rehearsal_shared_gpu"] = True
+    out["config"]["build"] = build_id()
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(prof):
         try:
             t = json.load(open(prof)).get(f"{a.mode}_border{a.border}_frames{a.frames}")
             if t:
+                # copied from the tracked profile of an EARLIER profiler run (separate --pmc passes): not measured
+                # by this run
                 out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_measured"] = False
                 out["roofline"]["traffic_source"] = t.get("source")
+                out["roofline"]["traffic_profile_build"] = t.get("build")
         except Exception:
             pass
 

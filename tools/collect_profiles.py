@@ -9,7 +9,7 @@ in KiB; on gfx950 FETCH_SIZE tallies a 128-B request as 64 B, so it is doubled
 -- confirmed here for THIS kernel's load shape by the calibration pass
 (tools/membench calib: known byte counts read with dword and dwordx4 loads).
 """
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, hashlib, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
@@ -19,13 +19,28 @@ os.makedirs(dst, exist_ok=True)
 num = rnd[1:].lstrip("0") or "0"
 tag = f"prof_r{num}"
 
+def build_id():  # the same id bench.py puts into config.build
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "disparity_to_point_cloud_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:12]
+
 def one(pattern):
-    fs = sorted(glob.glob(os.path.join(src, pattern)))
+    fs = sorted(glob.glob(os.path.join(src, pattern.replace("/*/", "/**/")), recursive=True))
     return fs[-1] if fs else None
 
 stats = one(f"{tag}_stats/*/*_kernel_stats.csv")
-if stats:
+if stats:  # the headline-only run (bench.py --no-variants): k_reproject_pack<F32> = the border-40 workload alone
     shutil.copy(stats, os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+stats_v = one(f"{tag}_stats_variants/*/*_kernel_stats.csv")
+if stats_v:  # the run with all side measurements: every other kernel of the library
+    shutil.copy(stats_v, os.path.join(dst, f"{rnd}_kernel_stats_variants.csv"))
+for suffix in ("under_rocprof", "under_rocprof_variants"):
+    b = os.path.join(src, f"bench_r{num}_{suffix}.json")
+    if os.path.exists(b) and os.path.getsize(b) > 0:
+        shutil.copy(b, os.path.join(dst, f"{rnd}_bench_{suffix}.json"))
 
 def counters(dirname):
     out = collections.defaultdict(list)
@@ -84,6 +99,7 @@ if main:
     rb = sum(fv) / len(fv) * 1024 * round(fetch_factor, 3); wb = sum(wv) / len(wv) * 1024
     traffic["parity_border40_frames16"] = {
         "hbm_bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb,
+        "build": build_id(),
         "source": f"profiles/{rnd}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                   f"FETCH_SIZE x{round(fetch_factor,3)} per calibration)"}
     cf = one(f"{tag}_cfetch/*/*_counter_collection.csv"); cw = one(f"{tag}_cwrite/*/*_counter_collection.csv")
@@ -95,7 +111,7 @@ if main:
         rb = sum(mean_of(cf, "FETCH_SIZE", k) for k in kerns) * 1024 * round(fetch_factor, 3)
         wb = sum(mean_of(cw, "WRITE_SIZE", k) for k in kerns) * 1024
         traffic["compact_border40_frames16"] = {
-            "hbm_bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb,
+            "hbm_bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb, "build": build_id(),
             "source": f"profiles/{rnd}_pmc_summary.json (all compaction kernels of one step: the single-pass kernel "
                       f"for launches of >= 4 frames and >= 24576 tiles, else count + scan + scatter)"}
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)

@@ -50,6 +50,14 @@ for name, pred in pats:
     streams[name] = s
     print(f"{name:12s} {n:3d} CUs: median11 {timed(med, s):8.1f} us   reproject u8 {timed(rep, s):8.1f} us", flush=True)
 
+# the fp32 headline kernel (16 x 4K, PARITY, border 40) on CU subsets: is it bound by the CUs or by the memory system?
+bf = DeviceBatch(ctx, N, H, W)
+bf.disp.copy_(torch.rand((N, H, W), device="cuda") * 127.5 + 0.5)
+for name in ("all", "first 192", "first 128", "last 64"):
+    us = timed(lambda s: bf.launch(stream=s), streams[name])
+    print(f"{name:12s}: k_reproject_pack<F32> {us:8.1f} us = {16 * 3760 * 2080 * 20 / us / 1e3:7.0f} GB/s", flush=True)
+del bf
+
 # concurrency: median on one masked stream, reprojection on the complementary one, started together
 for a, c in (("6 of 8", "2 of 8 (hi)"), ("7 of 8", "1 of 8 (hi)"), ("first 192", "last 64"), ("all", "all")):
     sa, sc = streams[a], (streams[c] if c != a else masked_stream(lambda i: True)[0])
