@@ -185,8 +185,8 @@ def cpu_baseline(q, border, budget_s=12.0):
     allc = W4K * H4K * m / el2 / 1e6
     return {
         "value": round(one, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-        "sample": f"{n} frames of 3840x2160 fp32 (config 4, border {border}), oracle/d2pc_oracle.c FORM_CV24, "
-                  f"{el:.1f} s",
+        "sample": f"{n} frames of 3840x2160 fp32 (config 4, border {border}), oracle/d2pc_oracle.c FORM_CV24 "
+                  f"(gcc -O3 -march=x86-64-v3 -ffp-contract=off), {el:.1f} s",
         "all_cores": {"value": round(allc, 2), "cores": nt, "sample": f"{m} frames, OpenMP over rows, {el2:.1f} s"},
     }
 
