@@ -66,7 +66,7 @@ struct d2pc_ctx {
   // (fast and slow devices agree on 2048-pixel tiles and 2-4 tiles per block)
   int pxt_parity = 8, pxt_compact = 8;
   int blocks_per_cu = 128;
-  int onepass_blocks_per_cu = 4;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each): 4 fit; sweep in profiles/r02_ab_onepass.txt
+  int onepass_blocks_per_cu = 0;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each: 4 fit); 0 = choose per launch
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
   int no_vec_rows = 0;
@@ -356,7 +356,10 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   if (a.compact_algo == 2) {
     // the single-pass kernel is software-pipelined over a block's tiles: it
     // wants few, long-lived blocks (about what is resident), not many short ones
-    const uint32_t persistent = uint32_t(ctx->cu_count) * uint32_t(ctx->onepass_blocks_per_cu);
+    // interleaved sweeps on two devices (profiles/r02_ab_onepass_v2_vs_r1.txt): 4K frames run 1-3 % faster with 3
+    // blocks per CU (fewer failed polls), 1080p-class frames 1-4 % faster with 4
+    const int per_cu = ctx->onepass_blocks_per_cu ? ctx->onepass_blocks_per_cu : (g.tiles_per_frame >= 2048 ? 3 : 4);
+    const uint32_t persistent = uint32_t(ctx->cu_count) * uint32_t(per_cu);
     a.grid = g.total_tiles < persistent ? g.total_tiles : persistent;
     if (a.grid < g.n_frames) a.compact_algo = 1;  // more frames than blocks: every block serves one frame only
   }
@@ -731,7 +734,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   if (!strcmp(key, "pxt_parity") && tile_shape_supported(value)) ctx->pxt_parity = value;
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
-  else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 1 && value <= 64) ctx->onepass_blocks_per_cu = value;
+  else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 0 && value <= 64) ctx->onepass_blocks_per_cu = value;
   else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
