@@ -64,7 +64,7 @@ struct d2pc_ctx {
   QStereo qs{};
   // tuning (d2pc_set_tuning); defaults from tools/ab.py sweeps on MI355X
   // (fast and slow devices agree on 2048-pixel tiles and 2-4 tiles per block)
-  int pxt_parity = 8, pxt_compact = 8;
+  int pxt_parity = 0, pxt_compact = 8;  // ROI pixels per thread; parity 0 = choose per launch (parity_pxt below)
   int blocks_per_cu = 128;
   int onepass_blocks_per_cu = 0;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each: 4 fit); 0 = choose per launch
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
@@ -148,6 +148,16 @@ int grow(d2pc_ctx *ctx, void **p, size_t *cap, size_t need) {
   return D2PC_OK;
 }
 
+// PARITY tile size: launches that leave the chip with few waves of blocks (one camera frame, a few 4K frames) run
+// 2-9 % faster with 1024-pixel tiles -- more blocks per CU to hide the load latency; big batches prefer 2048
+// (interleaved sweep, profiles/r02_sweep_small_launches.txt: equal at 8 x 4K, 2048 ahead from 16 x 4K / 256 x 752x480)
+int parity_pxt(const d2pc_ctx *ctx, int width, int height, int n_frames) {
+  if (ctx->pxt_parity) return ctx->pxt_parity;
+  const long long w = (long long)width - 2LL * ctx->cfg.border, h = (long long)height - 2LL * ctx->cfg.border;
+  const long long px = (w > 0 && h > 0 ? w * h : 0) * (long long)(n_frames > 0 ? n_frames : 1);
+  return px <= (32LL << 20) ? 4 : 8;
+}
+
 // Validates the frame description and fills the launch geometry.
 int make_geom(d2pc_ctx *ctx, int dtype, float scale, int width, int height, size_t row_stride,
               size_t in_frame_stride, int n_frames, size_t out_frame_stride, int pxt, Geom *g) {
@@ -201,6 +211,7 @@ int make_geom(d2pc_ctx *ctx, int dtype, float scale, int width, int height, size
   g->scale = scale;
   g->min_disparity = ctx->cfg.min_disparity;
   g->spin_ticks = uint32_t(ctx->spin_timeout_ms) * kSpinTicksPerMs;
+  g->pxt = uint32_t(pxt);
   return D2PC_OK;
 }
 
@@ -341,12 +352,12 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   a.grid = g.total_tiles < want ? g.total_tiles : want;
   if (a.grid == 0) a.grid = 1;
   if (ctx->cfg.mode == D2PC_MODE_PARITY) {
-    a.pxt = ctx->pxt_parity;
+    a.pxt = int(g.pxt);
     D2PC_HIP(ctx, launch_parity(a));
     return D2PC_OK;
   }
   if (!d_counts) return fail(ctx, D2PC_ERR_INVALID_ARG, "COMPACT mode needs a d_counts buffer");
-  a.pxt = ctx->pxt_compact;
+  a.pxt = int(g.pxt);
   // default (0): the single pass (one read of the input) wins once a launch is big enough to amortise
   // its pipeline fill -- measured crossover ~25k tiles (16 x 4K: 449 vs 495 us; 32 x 1080p: 196 vs 207;
   // 256 x 752x480: 278 vs 290; but 8 x 1080p: 68 vs 61) -- and needs a few frames in flight, because a
@@ -731,7 +742,7 @@ int d2pc_cloud_meta_fill(const d2pc_ctx *ctx, size_t n, d2pc_cloud_meta *m) {
 
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   if (!ctx || !key) return D2PC_ERR_INVALID_ARG;
-  if (!strcmp(key, "pxt_parity") && tile_shape_supported(value)) ctx->pxt_parity = value;
+  if (!strcmp(key, "pxt_parity") && (value == 0 || tile_shape_supported(value))) ctx->pxt_parity = value;
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 0 && value <= 64) ctx->onepass_blocks_per_cu = value;
@@ -780,7 +791,7 @@ int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scal
   const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
   Geom g;
   int st = make_geom(ctx, dtype, scale, width, height, row_stride, in_frame_stride, n_frames, out_frame_stride,
-                     compact ? ctx->pxt_compact : ctx->pxt_parity, &g);
+                     compact ? ctx->pxt_compact : parity_pxt(ctx, width, height, n_frames), &g);
   if (st != D2PC_OK) return st;
   if (reinterpret_cast<uintptr_t>(d_disp) % elem_size(dtype) != 0)
     return fail(ctx, D2PC_ERR_INVALID_ARG, "d_disp is not aligned to its sample type");
@@ -857,7 +868,7 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
   // device copies of the frame are packed to a 256-byte pitch
   const size_t pitch = (size_t(width > 0 ? width : 0) * es + 255) & ~size_t(255);
   const size_t kpitch = (size_t(width > 0 ? width : 0) * kes + 255) & ~size_t(255);
-  const int pxt = compact ? ctx->pxt_compact : ctx->pxt_parity;
+  const int pxt = compact ? ctx->pxt_compact : parity_pxt(ctx, width, height, 1);
   Geom g;
   int st = make_geom(ctx, dtype, scale, width, height, row_stride, 0, 1, 0, pxt, &g);  // validates the caller's stride
   if (st != D2PC_OK) return st;
@@ -1088,7 +1099,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
   const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
-  const int pxt = compact ? ctx->pxt_compact : ctx->pxt_parity;
+  const int pxt = compact ? ctx->pxt_compact : parity_pxt(ctx, width, height, n_frames);
   Geom gin;  // validates the caller's layout
   int st = make_geom(ctx, bridge16 ? int(D2PC_DTYPE_U16) : int(D2PC_DTYPE_U8), scale, width, height, row_stride,
                      frame_stride, n_frames, out_frame_stride, pxt, &gin);
@@ -1234,7 +1245,7 @@ int d2pc_pipeline_acquire(d2pc_ctx *ctx, const d2pc_frame_desc *desc, void **hos
   Geom g;  // validates dtype / size / stride of the caller's layout
   int st = make_geom(ctx, bridge16 ? int(D2PC_DTYPE_U16) : desc->dtype, desc->scale, desc->width, desc->height,
                      desc->row_stride_bytes, 0, 1, 0,
-                     ctx->cfg.mode == D2PC_MODE_COMPACT ? ctx->pxt_compact : ctx->pxt_parity, &g);
+                     ctx->cfg.mode == D2PC_MODE_COMPACT ? ctx->pxt_compact : parity_pxt(ctx, desc->width, desc->height, 1), &g);
   if (st != D2PC_OK) return st;
   int found = -1;
   for (int i = 0; i < ctx->pipe_depth; ++i)
@@ -1280,7 +1291,7 @@ int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
   const size_t kstride = bridge16 ? (size_t(d.width) + 255) & ~size_t(255) : d.row_stride_bytes;
   Geom g;
   int st = make_geom(ctx, kdtype, d.scale, d.width, d.height, kstride, 0, 1, 0,
-                     compact ? ctx->pxt_compact : ctx->pxt_parity, &g);
+                     compact ? ctx->pxt_compact : parity_pxt(ctx, d.width, d.height, 1), &g);
   if (st != D2PC_OK) return st;
   // the slot's buffers were sized at acquire time: a d2pc_set_border in between must not overflow them
   if (g.roi_n != sl.roi_n)

@@ -56,6 +56,7 @@ struct Geom {
   float scale;                        // U8/U16 decode: d = (float)raw*scale
   float min_disparity;                // compact predicate: drop d <= this
   uint32_t spin_ticks;                // single pass: hand-off wait budget in s_memrealtime ticks (100 MHz)
+  uint32_t pxt;                       // ROI pixels per thread the tile counts above were formed with (host side)
 };
 
 // Q_ (reference hpp:72): row-major 4x4 doubles.  Kernarg => scalar registers,
