@@ -588,6 +588,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restr
 // kernel 8 us for one 4K frame, a third of the scatter it feeds.
 // Leaves the exclusive prefix of tile i in partials[4*i].
 constexpr int kScanThreads = 1024, kScanBatch = 8;
+constexpr uint32_t kSelfScanTiles = 1024;  // frames up to this many tiles: the scatter kernel sums the counts itself
 __global__ __launch_bounds__(kScanThreads) void k_compact_scan(uint8_t *state, uint32_t *__restrict__ counts,
                                                                const Geom g) {
   __shared__ uint32_t s_w[kScanThreads / 64];
@@ -652,28 +653,50 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
                                                             float4 *__restrict__ out,
                                                             uint32_t *__restrict__ out_index,
                                                             uint32_t *__restrict__ counts, uint8_t *state,
-                                                            const Geom g, const QArg<QK> Q) {
+                                                            const Geom g, const QArg<QK> Q, const uint32_t selfscan) {
   constexpr int CELLS = PXT * (kBlock / 64);
   __shared__ uint32_t s_cnt[CELLS];
+  __shared__ uint32_t s_red[kBlock / 64];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   D2PC_DECLARE_STRIPS(VEC, wave);
   for (uint32_t t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
     const uint32_t f = fdiv(t, g.div_tpf);
     const uint32_t lt = t - f * g.tiles_per_frame;
     const uint32_t base = lt * uint32_t(kBlock * PXT);
+    const FrameState fs(state, g, f);
+    // selfscan (frames of <= kSelfScanTiles tiles: single camera frames): the block adds up the counts of the tiles
+    // before its own itself -- <= 16 KB from L2, requested ahead of the disparity loads -- and the scan kernel with
+    // its launch gap (a quarter of a 1080p frame's compaction time) is not launched at all
+    uint32_t before = 0;
+    if (selfscan) {
+      const uint4 *part = reinterpret_cast<const uint4 *>(fs.partials());
+      for (uint32_t i = tid; i < lt; i += uint32_t(kBlock)) {
+        const uint4 p = part[i];
+        before += p.x + p.y + p.z + p.w;
+      }
+    }
     TileRegs<DT, QK, PXT> r;
     uint64_t mask[PXT];
     tile_compute<DT, QK, PXT, VEC>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, base, wave, lane, wave_strip);
     tile_ballots<DT, QK, PXT>(r, g, base, wave, lane, mask);
+    if (selfscan) before = wave_sum(before);
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = uint32_t(__popcll(mask[k]));
+      s_red[wave] = before;
     }
     __syncthreads();
     uint32_t total;
     const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
-    const FrameState fs(state, g, f);
-    const uint32_t prefix = fs.partials()[4u * lt];  // exclusive prefix left by k_compact_scan (uniform load)
+    uint32_t prefix;
+    if (selfscan) {
+      prefix = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) prefix += s_red[w];
+      if (counts && lt == g.tiles_per_frame - 1 && tid == 0) counts[f] = prefix + total;
+    } else {
+      prefix = fs.partials()[4u * lt];  // exclusive prefix left by k_compact_scan (uniform load)
+    }
     float4 *fout = out + uint64_t(f) * g.out_frame_stride;
     uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
     tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane, g.roi_n);
@@ -1081,9 +1104,11 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
   if (a.compact_algo == 1) {  // count -> scan -> scatter: every state word is written before it is read
     hipLaunchKernelGGL((k_compact_count<DT, QK, PXT, VEC>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, state, a.geom,
                        make_qarg<QK>(a));
-    hipLaunchKernelGGL(k_compact_scan, dim3(a.geom.n_frames), dim3(kScanThreads), 0, a.stream, state, a.counts, a.geom);
+    const uint32_t selfscan = a.geom.tiles_per_frame <= kSelfScanTiles ? 1u : 0u;
+    if (!selfscan)
+      hipLaunchKernelGGL(k_compact_scan, dim3(a.geom.n_frames), dim3(kScanThreads), 0, a.stream, state, a.counts, a.geom);
     hipLaunchKernelGGL((k_compact_scatter<DT, QK, PXT, VEC>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, out,
-                       a.out_index, a.counts, state, a.geom, make_qarg<QK>(a));
+                       a.out_index, a.counts, state, a.geom, make_qarg<QK>(a), selfscan);
   } else {
     const uint32_t n16 = uint32_t((a.state_bytes + 15) / 16);  // buffers are allocated in whole MiB
     hipLaunchKernelGGL(k_state_clear, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(a.state), n16);
