@@ -274,6 +274,20 @@ def main():
     if a.share_gpu and a.backend != "gloo":
         raise SystemExit("--share-gpu needs --backend gloo")
 
+    # everything that can be refused is refused BEFORE a process group exists (a rank that dies inside
+    # init_process_group leaves its peers waiting for the launcher to reap them)
+    rank, local_rank, world = multi_gpu.env_world()
+    if world != max(a.gpus, 1):
+        raise SystemExit(f"bench.py: WORLD_SIZE {world} != --gpus {a.gpus} (start it as `python bench.py --gpus N` or "
+                         f"under torch.distributed.run with --nproc-per-node N)")
+    if torch.cuda.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if a.share_gpu:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but this node exposes "
+                         f"{torch.cuda.device_count()} GPU(s)")
+
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when its first
     # communicator comes up (the GPU boxes export NCCL_DEBUG=VERSION): fd 1 points at stderr until
     # the first collective is through.
@@ -289,16 +303,6 @@ def main():
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
-    if world != max(a.gpus, 1):
-        raise SystemExit(f"bench.py: WORLD_SIZE {world} != --gpus {a.gpus} (start it as `python bench.py --gpus N` or "
-                         f"under torch.distributed.run with --nproc-per-node N)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    if a.share_gpu:
-        local_rank = 0
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but this node exposes "
-                         f"{torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     mode = d2pc.MODE_PARITY if a.mode == "parity" else d2pc.MODE_COMPACT
