@@ -210,3 +210,14 @@ def test_pinned_payload_is_byte_identical_to_the_pageable_one(replay, tmp_path, 
     p2, d2 = _run(replay, "cloud", img, "mono16", tmp_path, "pinned", *extra)
     assert p2.returncode == 0, p2.stderr
     assert d2.read_bytes() == a
+
+
+def test_pinned_allocator_logic_on_the_cpu(tmp_path):
+    """host/pinned_allocator.hpp with counting stand-ins for d2pc_host_alloc/free: threshold, cache reuse, bounded
+    cache, default-initialising construct -- no GPU, under ASan + UBSan."""
+    exe = tmp_path / "pinned_allocator_test"
+    src = os.path.join(ROOT, "tests", "cpp", "pinned_allocator_test.cpp")
+    subprocess.run(["g++", "-std=c++14", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined",
+                    "-fno-omit-frame-pointer", "-o", str(exe), src], check=True, capture_output=True, timeout=180)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "pinned allocator ok" in p.stdout, p.stdout + p.stderr
