@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_NAME = "libd2pc.so"
+# D2PC_LIBRARY_VARIANT=x loads libd2pc_x.so (tuning builds of `make variant NAME=x`; tools and soak runs only)
+_LIB_NAME = ("libd2pc_%s.so" % os.environ["D2PC_LIBRARY_VARIANT"]) if os.environ.get("D2PC_LIBRARY_VARIANT") else "libd2pc.so"
 
 DTYPE_F32, DTYPE_U8, DTYPE_U16, DTYPE_MONO16 = 0, 1, 2, 3
 MODE_PARITY, MODE_COMPACT = 0, 1
