@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--launches", type=int, default=6)
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--scale", type=float, default=None)
+    ap.add_argument("--tune", action="append", default=[], help="key=value for d2pc_set_tuning (repeatable)")
     a = ap.parse_args()
     if WORKLOADS[a.workload][0] == "median":   # k_median_u8<11> over the inset ROI, 16 x 4K (cpp:55-57)
         _, F, W, H, border, *_ = WORKLOADS[a.workload]
@@ -70,7 +71,7 @@ def main():
         print(json.dumps({"workload": a.workload, "launches": a.launches, "ms_per_launch": round(ms, 4), "points": px,
                           "roi_pixels": px, "algorithmic_bytes": 2 * px, "algorithmic_GBs": round(2 * px / ms / 1e6, 1)}))
         return
-    ctx, b = make_batch(a.workload, a.algo)
+    ctx, b = make_batch(a.workload, a.algo, tuning=[(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.tune])
     scale = a.scale if a.scale is not None else (0.125 if b.disp.dtype == torch.uint8 else 1.0)
     b.launch(scale=scale)
     torch.cuda.synchronize()
