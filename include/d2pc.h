@@ -446,9 +446,10 @@ typedef struct d2pc_stage_times {
 int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
 
 /* Launch-shape tuning hook (no counterpart in the reference; results never
- * depend on it).  Keys: "pxt_parity", "pxt_compact" (ROI pixels per thread:
- * 4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by the tile count; 1..4096),
- * "onepass_blocks_per_cu", "force_general_q", "no_vec_rows", "fuse_rows" (rows per wave of
+ * depend on it).  Keys: "pxt_parity" (ROI pixels per thread: 4, 8 or 16; 0 = choose per launch -- 4 up to
+ * 32 Mpixel, 8 above), "pxt_compact" (4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by
+ * the tile count; 1..4096), "onepass_blocks_per_cu" (persistent blocks per CU of the single pass; 0 = choose:
+ * 3 for 4K-class frames, 4 below), "force_general_q", "no_vec_rows", "fuse_rows" (rows per wave of
  * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
  * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
  * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap). */

@@ -233,3 +233,29 @@ def test_capture_without_a_reserved_state_buffer_fails_cleanly():
             except d2pc.D2pcError as e:
                 err = e
         assert err is not None and "d2pc_reserve" in str(err)
+
+
+def test_async_error_check_is_per_state_buffer():
+    """A big single-pass launch on one stream followed by a small two-pass launch on another: the check must look at
+    each buffer's OWN last algorithm (round 1 keyed on the context's last launch and could skip the big one's
+    header, or read a stale flag through the small one)."""
+    q = d2pc.make_q()
+    big = [synth_disparity(3, 500 + f, 1920, 1080, "holes") for f in range(30)]   # 27k tiles: single pass
+    small = [synth_disparity(2, 600 + f, 320, 240, "holes") for f in range(2)]    # two-pass
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        bb, bs = _batch(ctx, big, want_index=False), _batch(ctx, small, want_index=True)
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            bb.launch(stream=sa)
+            bs.launch(stream=sb)
+        torch.cuda.synchronize()
+        ctx.check_async_error()
+        rs = bs.results()
+        counts = bb.counts.cpu().numpy().view(np.uint32)
+    assert not np.any(counts == 0xFFFFFFFF)
+    for f, (pts, idx) in enumerate(rs):
+        wp, wi = oracle.reproject_compact(small[f], q, border=40)
+        assert np.array_equal(idx, wi)
+        assert_points_close(pts, wp, max_ulp=1)
+    assert int(counts[0]) == len(oracle.reproject_compact(big[0], q, border=40)[0])
