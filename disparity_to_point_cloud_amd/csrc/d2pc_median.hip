@@ -26,170 +26,23 @@
 #include <stdint.h>
 
 #include "d2pc_launch.hpp"
+#include "d2pc_median_tile.hpp"
 
 namespace d2pc {
-
-namespace {
-
-template <int KS>
-struct MedianShape {
-  static constexpr int R = KS / 2;
-  static constexpr int SEG_PX = 17 - KS;           // output pixels served by one 16-bit segment
-  static constexpr int NSEG = 16 / SEG_PX + 1;     // segments cut from a 32-bit plane word
-  static constexpr int TW = NSEG * SEG_PX;         // tile width  (k=11: 18, 9: 24, 7: 20, 5: 24, 3: 28)
-  static constexpr int TH = 64;                    // tile height
-  static constexpr int IN_ROWS = TH + 2 * R;
-  static constexpr int NREG = (KS + 1) / 2;        // row pairs per window
-  // Small windows: a thread selects for TWO horizontally adjacent pixels (they share every pair word:
-  // 3x3 +6 %, same device); at 9x9 and 11x11 the second pixel's registers cost a wave of occupancy (-3 %).
-  static constexpr int NPX = KS <= 5 ? 2 : 1;
-  static constexpr int ITEMS = TW / NPX * TH;
-  static constexpr int THREADS = ITEMS % 256 == 0 ? 256 : ITEMS % 192 == 0 ? 192 : ITEMS % 320 == 0 ? 320 : 128;
-  static_assert(SEG_PX % 2 == 0 && TW % 2 == 0, "a pixel pair never straddles two segments");
-  static_assert((NSEG - 1) * SEG_PX + 16 <= 32, "segments must lie inside the plane word");
-  static_assert(TW + KS - 1 <= 32, "the tile's windows must lie inside the plane word");
-  static_assert(ITEMS % THREADS == 0, "whole passes over the tile");
-  static_assert(IN_ROWS <= 2 * 63 && THREADS >= 128, "two waves of 63 row pairs cover the input rows");
-};
-
-}  // namespace
 
 template <int KS>
 __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const uint8_t *__restrict__ src,
                                                                         uint8_t *__restrict__ dst,
                                                                         const MedianArgs a) {
   using S = MedianShape<KS>;
-  constexpr int R = S::R, IN_ROWS = S::IN_ROWS;
-  __shared__ uint32_t s_pair[8][S::NSEG][IN_ROWS];
-  const uint32_t tid = threadIdx.x;
-
+  __shared__ uint32_t s_pair[8][S::NSEG][S::IN_ROWS];
   uint32_t b = blockIdx.x;
   const uint32_t f = b / (a.tiles_x * a.tiles_y);
   b -= f * a.tiles_x * a.tiles_y;
   const uint32_t ty = b / a.tiles_x, tx = b - ty * a.tiles_x;
   const int c0 = int(a.out_x0) + int(tx) * S::TW, y0 = int(a.out_y0) + int(ty) * S::TH;
-  const uint8_t *fsrc = src + uint64_t(f) * a.src_frame_stride;
-  uint8_t *fdst = dst + uint64_t(f) * a.dst_frame_stride;
-
-  // ---- 1. packed plane segments of the tile's input rows: one LANE per row ---------
-  // Wave w takes input rows 63w .. 63w+63: lane l needs the plane words of the row below it, which
-  // lane l+1 of the SAME wave holds (one DPP move per plane); lane 63 only serves as that partner,
-  // its own row is lane 0 of the next wave.  Two waves cover the <= 74 rows.
-  const uint32_t lane = tid & 63u;
-  const uint32_t in_row = (tid >> 6) * 63u + lane;
-  if ((tid >> 6) * 63u < uint32_t(IN_ROWS)) {  // wave-uniform
-    int iy = y0 - R + int(in_row);
-    iy = iy < 0 ? 0 : iy >= int(a.height) ? int(a.height) - 1 : iy;  // replicate (also keeps rows past IN_ROWS in bounds)
-    const uint8_t *row = fsrc + uint64_t(iy) * a.src_row_stride;
-    const int cl = c0 - R;  // column of bit 0
-    uint32_t px[8];         // pixels cl .. cl+31, four per dword
-    if (cl >= 0 && cl + 31 < int(a.width)) {  // block-uniform: interior tile
-      __builtin_memcpy(px, row + cl, 32);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        px[j] = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          int ix = cl + 4 * j + k;
-          ix = ix < 0 ? 0 : ix >= int(a.width) ? int(a.width) - 1 : ix;  // replicate
-          px[j] |= uint32_t(row[ix]) << (8 * k);
-        }
-      }
-    }
-    // 8 pixels (lo = pixels 0..3, hi = 4..7) -> byte p of (lo, hi) = bit p of the 8 pixels
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      uint32_t lo = px[j], hi = px[j + 1], t;
-      t = (lo ^ (lo >> 7)) & 0x00aa00aau, lo ^= t ^ (t << 7);
-      t = (hi ^ (hi >> 7)) & 0x00aa00aau, hi ^= t ^ (t << 7);
-      t = (lo ^ (lo >> 14)) & 0x0000ccccu, lo ^= t ^ (t << 14);
-      t = (hi ^ (hi >> 14)) & 0x0000ccccu, hi ^= t ^ (t << 14);
-      t = (lo ^ ((lo >> 28) | (hi << 4))) & 0xf0f0f0f0u;
-      lo ^= t ^ (t << 28);
-      hi ^= t >> 4;
-      px[j] = lo, px[j + 1] = hi;
-    }
-    // plane p = byte p of the four blocks: a 4x4 byte transpose of the lows (planes 0..3) and of the highs
-    uint32_t plane[8];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint32_t b0 = px[h], b1 = px[2 + h], b2 = px[4 + h], b3 = px[6 + h];
-      const uint32_t a0 = __builtin_amdgcn_perm(b1, b0, 0x05010400u), a1 = __builtin_amdgcn_perm(b1, b0, 0x07030602u);
-      const uint32_t a2 = __builtin_amdgcn_perm(b3, b2, 0x05010400u), a3 = __builtin_amdgcn_perm(b3, b2, 0x07030602u);
-      plane[4 * h + 0] = __builtin_amdgcn_perm(a2, a0, 0x05040100u);
-      plane[4 * h + 1] = __builtin_amdgcn_perm(a2, a0, 0x07060302u);
-      plane[4 * h + 2] = __builtin_amdgcn_perm(a3, a1, 0x05040100u);
-      plane[4 * h + 3] = __builtin_amdgcn_perm(a3, a1, 0x07060302u);
-    }
-    // 16-bit segments of this row and the next, packed
-    const bool writer = lane < 63u && in_row < uint32_t(IN_ROWS);
-#pragma unroll
-    for (int pl = 0; pl < 8; ++pl) {
-      const uint32_t below = uint32_t(__builtin_amdgcn_update_dpp(0, int(plane[pl]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-#pragma unroll
-      for (int sg = 0; sg < S::NSEG; ++sg) {
-        const uint32_t v = ((plane[pl] >> (sg * S::SEG_PX)) & 0xffffu) | ((below >> (sg * S::SEG_PX)) << 16);
-        if (writer) s_pair[pl][sg][in_row] = v;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- 2. radix select, NPX horizontally adjacent pixels per thread ------------------------------
-  constexpr uint32_t kField = (1u << KS) - 1u;
-  constexpr int NPX = S::NPX;
-#pragma unroll 1
-  for (int it = 0; it < S::ITEMS / S::THREADS; ++it) {
-    const uint32_t p = tid + uint32_t(it) * uint32_t(S::THREADS);
-    const uint32_t y = p / uint32_t(S::TW / NPX), x = uint32_t(NPX) * (p - y * uint32_t(S::TW / NPX));
-    const uint32_t sg = x / uint32_t(S::SEG_PX), xs = x - sg * uint32_t(S::SEG_PX);
-    uint32_t cand[NPX][S::NREG];
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) {
-      const uint32_t one_row = kField << (xs + uint32_t(q));  // <= 16 bits by construction
-#pragma unroll
-      for (int j = 0; j < S::NREG; ++j) cand[q][j] = one_row | (one_row << 16);
-      if (KS & 1) cand[q][S::NREG - 1] = one_row;  // the last register holds one window row only
-    }
-    // With c candidates left and the median the (a+1)-th smallest of them, only d = c - a - 1 has to
-    // be carried: the median's bit is 1  <=>  zeros <= a  <=>  z = d - ones < 0; then d stays (c and a
-    // shrink by the same number of zeros), otherwise d = z.  Five integer ops per plane.
-    int32_t d[NPX], acc[NPX];  // acc: minus the median, built MSB first
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) d[q] = KS * KS - (KS * KS / 2 + 1), acc[q] = 0;
-#pragma unroll
-    for (int pl = 7; pl >= 0; --pl) {
-      uint32_t word[S::NREG];
-#pragma unroll
-      for (int j = 0; j < S::NREG; ++j) word[j] = s_pair[pl][sg][y + 2u * uint32_t(j)];
-#pragma unroll
-      for (int q = 0; q < NPX; ++q) {
-        uint32_t n1 = 0;
-#pragma unroll
-        for (int j = 0; j < S::NREG; ++j) n1 += uint32_t(__popc(cand[q][j] & word[j]));
-        const int32_t z = d[q] - int32_t(n1);
-        const int32_t is1 = z >> 31;  // all ones when the median's bit is 1
-        // keep the candidates whose bit equals the median's: cand & ~(word ^ is1) is ONE v_bitop3 per
-        // register (as an intrinsic: written with operators, LLVM folds it into the next plane's AND
-        // and spends a fourth instruction on the shared term)
-        if (pl > 0) {
-#pragma unroll
-          for (int j = 0; j < S::NREG; ++j)
-            cand[q][j] = __builtin_amdgcn_bitop3_b32(word[j], cand[q][j], uint32_t(is1), 0x84);
-        }
-        d[q] = z + (int32_t(n1) & is1);
-        acc[q] = (acc[q] << 1) + is1;
-      }
-    }
-    const uint32_t oy = uint32_t(y0) + y, ox = uint32_t(c0) + x;
-    if (oy < a.out_y0 + a.out_h) {
-      uint8_t *o = fdst + uint64_t(oy) * a.dst_row_stride + ox;
-#pragma unroll
-      for (int q = 0; q < NPX; ++q)
-        if (ox + uint32_t(q) < a.out_x0 + a.out_w) o[q] = uint8_t(-acc[q]);
-    }
-  }
+  median_tile<KS, false>(src + uint64_t(f) * a.src_frame_stride, dst + uint64_t(f) * a.dst_frame_stride, a, c0, y0, s_pair,
+                         threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------

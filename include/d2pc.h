@@ -300,7 +300,12 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
  * arithmetic competes with the filter for the same VALUs -- and every
  * cross-stream dependency of a real pipeline costs ~20 us, so 2 chunks of
  * 16 x 4K ranged from +8 % to -10 % between devices and finer chunks were
- * always slower than no overlap.  Results never depend on the setting.
+ * always slower than no overlap.  The one-kernel form the overlap really wants -- a
+ * persistent kernel whose blocks switch between filter tiles and reprojection tiles,
+ * handing frames over in-kernel -- exists as well (tuning key "callback_fused",
+ * 11 x 11 / 8-bit / PARITY batches; bit-identical output) and is off for the same
+ * reason: 1.4x SLOWER than the two launches (DESIGN.md section 9 says why).
+ * Results never depend on either setting.
  * The filtered frames live in context-owned scratch (grown on demand, so the
  * first call of a size is not capturable; under stream capture the call runs
  * in order on `stream`).
@@ -452,7 +457,8 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * 3 for 4K-class frames, 4 below), "force_general_q", "no_vec_rows", "fuse_rows" (rows per wave of
  * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
  * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
- * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap). */
+ * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
+ * "callback_fused" (0/1: the heterogeneous persistent kernel there; default 0). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

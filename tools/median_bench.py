@@ -40,7 +40,14 @@ for (w, h, n) in ((752, 480, 64), (1920, 1080, 16), (3840, 2160, 16)):
         b.launch(scale=0.125)
     us = t(body)
     us_r = t(lambda: b.launch(scale=0.125))
-    for chunks in (1, 2, 4):
+    for fused in (1, 0):
+        ctx.set_tuning("callback_fused", fused); ctx.set_tuning("callback_chunks", 1)
+        uf = t(lambda: ctx.process_mono_device(raw.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125,
+                                               b.points.data_ptr(), None, b.stride, b.counts.data_ptr(), s))
+        print(f"{w}x{h} x{n}: d2pc_process_mono_device callback_fused={fused}: {uf:8.1f} us = "
+              f"{n*w*h/uf:9.1f} Mpix/s  ({us/uf:.3f}x the two launches in order)", flush=True)
+    ctx.set_tuning("callback_fused", 0)
+    for chunks in (2, 4):
         ctx.set_tuning("callback_chunks", chunks)
         uf = t(lambda: ctx.process_mono_device(raw.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125,
                                                b.points.data_ptr(), None, b.stride, b.counts.data_ptr(), s))
