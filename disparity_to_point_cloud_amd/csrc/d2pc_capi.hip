@@ -75,6 +75,7 @@ struct d2pc_ctx {
   d2pc_stage_times times{};
   bool have_times = false;
   int fuse_rows = 0;             // d2pc_fuse_device rows per wave: 0 = choose, else 2..1024
+  int median_algo = 0;           // MedianArgs::algo: 0 choose per launch, 1 per-pixel select, 2 bit-sliced (k = 9, 11)
   // device scratch
   StateBuf states[kMaxStateBufs];  // compaction state, one per stream with COMPACT work in flight
   size_t state_reserve = 0;        // d2pc_reserve: every buffer is at least this large
@@ -754,6 +755,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "callback_chunks") && value >= 0 && value <= 64) ctx->cb_chunks = value;
   else if (!strcmp(key, "callback_fused") && (value == 0 || value == 1)) ctx->cb_fused = value;
+  else if (!strcmp(key, "median_algo") && value >= 0 && value <= 2) ctx->median_algo = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
   return D2PC_OK;
@@ -907,6 +909,7 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
   D2PC_HIP(ctx, mark(1));
   const void *kernel_in = ctx->d_in;
   MedianArgs m;
+  m.algo = ctx->median_algo;
   m.width = uint32_t(width);
   m.height = uint32_t(height);
   if (bridge16) {
@@ -1001,6 +1004,7 @@ int d2pc_mono16_to_mono8_device(d2pc_ctx *ctx, const void *d_src, int width, int
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
   MedianArgs m;
+  m.algo = ctx->median_algo;
   m.width = uint32_t(width);
   m.height = uint32_t(height);
   m.n_frames = uint32_t(n_frames);
@@ -1028,6 +1032,7 @@ static int median_device(d2pc_ctx *ctx, const void *d_src, int width, int height
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
   MedianArgs m;
+  m.algo = ctx->median_algo;
   m.width = uint32_t(width);
   m.height = uint32_t(height);
   m.n_frames = uint32_t(n_frames);
@@ -1145,6 +1150,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
     a.qs = ctx->qs;
     a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
     MedianArgs m;
+    m.algo = ctx->median_algo;
     m.width = uint32_t(width);
     m.height = uint32_t(height);
     m.n_frames = uint32_t(n_frames);
@@ -1187,6 +1193,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
     const void *kin = src;
     size_t kin_pitch = row_stride, kin_frame = frame_stride;
     MedianArgs m;
+    m.algo = ctx->median_algo;
     m.width = uint32_t(width);
     m.height = uint32_t(height);
     m.n_frames = uint32_t(nf);
@@ -1352,6 +1359,7 @@ int d2pc_pipeline_submit(d2pc_ctx *ctx, int slot) {
   D2PC_HIP(ctx, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, s));
   const void *kin = sl.d_in;
   MedianArgs m;
+  m.algo = ctx->median_algo;
   m.width = uint32_t(d.width);
   m.height = uint32_t(d.height);
   if (bridge16) {

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_callback_fused(
   // A reprojection tile is therefore WAVES x 8 slots x 64 pixels, batches of WAVES x 256.
   using S = MedianShape<KS>;
   constexpr uint32_t WAVES = S::THREADS / 64, RBATCH = WAVES * 256u, RTILE = uint32_t(S::THREADS) * PXT;
-  __shared__ uint32_t s_pair[8][S::NSEG][S::IN_ROWS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pair[S::LDS_WORDS];
   __shared__ uint32_t s_cmd[4];  // {kind, first, count, -}
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t m_per_frame = ma.tiles_x * ma.tiles_y, m_total = m_per_frame * ma.n_frames;

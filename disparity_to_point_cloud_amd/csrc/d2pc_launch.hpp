@@ -40,8 +40,13 @@ struct MedianArgs {
   // inset ROI (cpp:70,72 read nothing else of the filtered image).
   uint32_t out_x0 = 0, out_y0 = 0, out_w = 0, out_h = 0;
   uint32_t tiles_x = 0, tiles_y = 0;                // filled by launch_median
+  // 0: choose per launch; 1: one pixel per thread (d2pc_median.hip); 2: bit-sliced across pixels
+  // (d2pc_median_bs.hip; k = 9 and 11 only, otherwise 1 is taken)
+  int algo = 0;
 };
 bool median_ksize_supported(int k);
+uint64_t median_bs_tiles(const MedianArgs &a);  // a.out_* resolved
+hipError_t launch_median_bs(const void *src, void *dst, const MedianArgs &a, int ksize, hipStream_t stream);
 hipError_t launch_median(const void *src, void *dst, const MedianArgs &a, int ksize, hipStream_t stream);
 // cv_bridge mono16 -> mono8 (d2pc_median.hip); strides in bytes, src rows hold uint16
 hipError_t launch_mono16_to_mono8(const void *src, void *dst, const MedianArgs &a, hipStream_t stream);

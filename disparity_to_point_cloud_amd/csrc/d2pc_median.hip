@@ -35,7 +35,7 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const ui
                                                                         uint8_t *__restrict__ dst,
                                                                         const MedianArgs a) {
   using S = MedianShape<KS>;
-  __shared__ uint32_t s_pair[8][S::NSEG][S::IN_ROWS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pair[S::LDS_WORDS];
   uint32_t b = blockIdx.x;
   const uint32_t f = b / (a.tiles_x * a.tiles_y);
   b -= f * a.tiles_x * a.tiles_y;
@@ -98,12 +98,6 @@ namespace {
 template <int KS>
 hipError_t launch_k(const uint8_t *s, uint8_t *d, MedianArgs a, hipStream_t stream) {
   using S = MedianShape<KS>;
-  if (a.out_w == 0 || a.out_h == 0) {  // whole image
-    a.out_x0 = a.out_y0 = 0;
-    a.out_w = a.width;
-    a.out_h = a.height;
-  }
-  if (a.out_x0 + a.out_w > a.width || a.out_y0 + a.out_h > a.height) return hipErrorInvalidValue;
   a.tiles_x = (a.out_w + S::TW - 1) / S::TW;
   a.tiles_y = (a.out_h + S::TH - 1) / S::TH;
   const uint64_t blocks = uint64_t(a.tiles_x) * a.tiles_y * a.n_frames;
@@ -113,9 +107,24 @@ hipError_t launch_k(const uint8_t *s, uint8_t *d, MedianArgs a, hipStream_t stre
 }
 }  // namespace
 
-hipError_t launch_median(const void *src, void *dst, const MedianArgs &a, int ksize, hipStream_t stream) {
+// The bit-sliced kernel works on 256 x 32 tiles, three 4-wave blocks per CU, ~20 us per block: it pays once
+// the launch has about two thirds of a chipful of tiles (profiles/r02_median_bitsliced.txt: 312 tiles 0.86x,
+// 512 tiles 1.11x, 15,600 tiles 1.46x the per-pixel kernel); below that (one native 752x480 frame is 39
+// tiles, 7 us) the per-pixel kernel's 18 x 64 tiles spread better.
+constexpr uint64_t kBsMinTiles = 448;
+
+hipError_t launch_median(const void *src, void *dst, const MedianArgs &args, int ksize, hipStream_t stream) {
   const uint8_t *s = static_cast<const uint8_t *>(src);
   uint8_t *d = static_cast<uint8_t *>(dst);
+  MedianArgs a = args;
+  if (a.out_w == 0 || a.out_h == 0) {  // whole image
+    a.out_x0 = a.out_y0 = 0;
+    a.out_w = a.width;
+    a.out_h = a.height;
+  }
+  if (a.out_x0 + a.out_w > a.width || a.out_y0 + a.out_h > a.height) return hipErrorInvalidValue;
+  if ((ksize == 9 || ksize == 11) && (a.algo == 2 || (a.algo == 0 && median_bs_tiles(a) >= kBsMinTiles)))
+    return launch_median_bs(src, dst, a, ksize, stream);
   switch (ksize) {
     case 3: return launch_k<3>(s, d, a, stream);
     case 5: return launch_k<5>(s, d, a, stream);

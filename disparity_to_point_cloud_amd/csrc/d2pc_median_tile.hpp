@@ -47,6 +47,12 @@ struct MedianShape {
   static constexpr int NPX = KS <= 5 ? 2 : 1;
   static constexpr int ITEMS = TW / NPX * TH;
   static constexpr int THREADS = ITEMS % 256 == 0 ? 256 : ITEMS % 192 == 0 ? 192 : ITEMS % 320 == 0 ? 320 : 128;
+  // LDS: pair[segment][input row][plane] -- the eight planes of a row pair side by side, so that the select
+  // loop reads four planes with one ds_read_b128 (256 B/clk/CU; ds_read2_b32/_b64 get half that) at an
+  // immediate offset from ONE base address per pixel; the segments are four dwords (banks) apart so that
+  // the three segments a 16-lane group touches do not collide
+  static constexpr int SG_STRIDE = IN_ROWS * 8 + 4;
+  static constexpr int LDS_WORDS = NSEG * SG_STRIDE;
   static_assert(SEG_PX % 2 == 0 && TW % 2 == 0, "a pixel pair never straddles two segments");
   static_assert((NSEG - 1) * SEG_PX + 16 <= 32, "segments must lie inside the plane word");
   static_assert(TW + KS - 1 <= 32, "the tile's windows must lie inside the plane word");
@@ -62,8 +68,7 @@ struct MedianShape {
 template <int KS, bool COHERENT>
 __device__ __forceinline__ void median_tile(const uint8_t *__restrict__ fsrc, uint8_t *__restrict__ fdst,
                                             const MedianArgs &a, const int c0, const int y0,
-                                            uint32_t (&s_pair)[8][MedianShape<KS>::NSEG][MedianShape<KS>::IN_ROWS],
-                                            const uint32_t tid) {
+                                            uint32_t (&s_pair)[MedianShape<KS>::LDS_WORDS], const uint32_t tid) {
   using S = MedianShape<KS>;
   constexpr int R = S::R, IN_ROWS = S::IN_ROWS;
   const bool active = tid < uint32_t(S::THREADS);  // wave-uniform (THREADS is a multiple of 64)
@@ -120,13 +125,19 @@ __device__ __forceinline__ void median_tile(const uint8_t *__restrict__ fsrc, ui
     }
     // 16-bit segments of this row and the next, packed
     const bool writer = lane < 63u && in_row < uint32_t(IN_ROWS);
+    uint32_t below[8];
 #pragma unroll
-    for (int pl = 0; pl < 8; ++pl) {
-      const uint32_t below = uint32_t(__builtin_amdgcn_update_dpp(0, int(plane[pl]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    for (int pl = 0; pl < 8; ++pl)
+      below[pl] = uint32_t(__builtin_amdgcn_update_dpp(0, int(plane[pl]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 #pragma unroll
-      for (int sg = 0; sg < S::NSEG; ++sg) {
-        const uint32_t v = ((plane[pl] >> (sg * S::SEG_PX)) & 0xffffu) | ((below >> (sg * S::SEG_PX)) << 16);
-        if (writer) s_pair[pl][sg][in_row] = v;
+    for (int sg = 0; sg < S::NSEG; ++sg) {
+#pragma unroll
+      for (int pl = 0; pl < 8; pl += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          v[i] = ((plane[pl + i] >> (sg * S::SEG_PX)) & 0xffffu) | ((below[pl + i] >> (sg * S::SEG_PX)) << 16);
+        if (writer) *reinterpret_cast<uint4 *>(&s_pair[sg * S::SG_STRIDE + int(in_row) * 8 + pl]) = make_uint4(v[0], v[1], v[2], v[3]);
       }
     }
   }
@@ -135,11 +146,12 @@ __device__ __forceinline__ void median_tile(const uint8_t *__restrict__ fsrc, ui
   // ---- 2. radix select, NPX horizontally adjacent pixels per thread ------------------------------
   constexpr uint32_t kField = (1u << KS) - 1u;
   constexpr int NPX = S::NPX;
+  constexpr uint32_t TWP = S::TW / NPX;  // items per tile row; item p = tid + it * THREADS sits at (p / TWP, NPX * (p % TWP))
+  uint32_t y = tid / TWP, x = uint32_t(NPX) * (tid - y * TWP);
 #pragma unroll 1
   for (int it = 0; active && it < S::ITEMS / S::THREADS; ++it) {
-    const uint32_t p = tid + uint32_t(it) * uint32_t(S::THREADS);
-    const uint32_t y = p / uint32_t(S::TW / NPX), x = uint32_t(NPX) * (p - y * uint32_t(S::TW / NPX));
     const uint32_t sg = x / uint32_t(S::SEG_PX), xs = x - sg * uint32_t(S::SEG_PX);
+    const uint32_t *base = &s_pair[sg * uint32_t(S::SG_STRIDE) + y * 8u];
     uint32_t cand[NPX][S::NREG];
 #pragma unroll
     for (int q = 0; q < NPX; ++q) {
@@ -148,34 +160,46 @@ __device__ __forceinline__ void median_tile(const uint8_t *__restrict__ fsrc, ui
       for (int j = 0; j < S::NREG; ++j) cand[q][j] = one_row | (one_row << 16);
       if (KS & 1) cand[q][S::NREG - 1] = one_row;  // the last register holds one window row only
     }
-    // With c candidates left and the median the (a+1)-th smallest of them, only d = c - a - 1 has to
-    // be carried: the median's bit is 1  <=>  zeros <= a  <=>  z = d - ones < 0; then d stays (c and a
-    // shrink by the same number of zeros), otherwise d = z.  Five integer ops per plane.
-    int32_t d[NPX], acc[NPX];  // acc: minus the median, built MSB first
+    // With c candidates left and the median the (a+1)-th smallest of them, only d = c - a - 1 has to be
+    // carried, as m = -d - 1 < 0: the popcounts of a plane accumulate ON m (v_bcnt's addend), e = m + ones,
+    // and the median's bit is 0  <=>  ones <= d  <=>  e < 0.  Then d becomes d - ones (m = e), otherwise it
+    // stays: m = max_u32(e, m) covers both (e >= m as signed numbers; a non-negative e is the smaller
+    // unsigned).  Three integer ops per plane next to the three per register.
+    int32_t m[NPX], acc[NPX];  // acc: minus the number of zero bits' weights = median - 255, built MSB first
 #pragma unroll
-    for (int q = 0; q < NPX; ++q) d[q] = KS * KS - (KS * KS / 2 + 1), acc[q] = 0;
+    for (int q = 0; q < NPX; ++q) m[q] = -(KS * KS - (KS * KS / 2 + 1)) - 1, acc[q] = 0;
 #pragma unroll
-    for (int pl = 7; pl >= 0; --pl) {
-      uint32_t word[S::NREG];
+    for (int ph = 1; ph >= 0; --ph) {  // planes 7..4, then 3..0: four planes of a row pair are ONE ds_read_b128
+      uint4 w4[S::NREG];
 #pragma unroll
-      for (int j = 0; j < S::NREG; ++j) word[j] = s_pair[pl][sg][y + 2u * uint32_t(j)];
+      for (int j = 0; j < S::NREG; ++j) w4[j] = *reinterpret_cast<const uint4 *>(base + 16 * j + 4 * ph);
 #pragma unroll
-      for (int q = 0; q < NPX; ++q) {
-        uint32_t n1 = 0;
+      for (int h = 3; h >= 0; --h) {
+        uint32_t word[S::NREG];
 #pragma unroll
-        for (int j = 0; j < S::NREG; ++j) n1 += uint32_t(__popc(cand[q][j] & word[j]));
-        const int32_t z = d[q] - int32_t(n1);
-        const int32_t is1 = z >> 31;  // all ones when the median's bit is 1
-        // keep the candidates whose bit equals the median's: cand & ~(word ^ is1) is ONE v_bitop3 per
-        // register (as an intrinsic: written with operators, LLVM folds it into the next plane's AND
-        // and spends a fourth instruction on the shared term)
-        if (pl > 0) {
+        for (int j = 0; j < S::NREG; ++j) word[j] = h == 3 ? w4[j].w : h == 2 ? w4[j].z : h == 1 ? w4[j].y : w4[j].x;
 #pragma unroll
-          for (int j = 0; j < S::NREG; ++j)
-            cand[q][j] = __builtin_amdgcn_bitop3_b32(word[j], cand[q][j], uint32_t(is1), 0x84);
+        for (int q = 0; q < NPX; ++q) {
+          uint32_t e = uint32_t(m[q]);
+#pragma unroll
+          for (int j = 0; j < S::NREG; ++j) {
+            // a chain of accumulating popcounts (written with operators, LLVM re-associates it into a tree
+            // with extra additions)
+            const uint32_t ones = cand[q][j] & word[j];
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(e) : "v"(ones), "v"(e));
+          }
+          const int32_t is0 = int32_t(e) >> 31;  // all ones when the median's bit is 0
+          // keep the candidates whose bit equals the median's: cand & (word ^ is0) is ONE v_bitop3 per
+          // register (as an intrinsic: written with operators, LLVM folds it into the next plane's AND
+          // and spends a fourth instruction on the shared term)
+          if (ph > 0 || h > 0) {
+#pragma unroll
+            for (int j = 0; j < S::NREG; ++j)
+              cand[q][j] = __builtin_amdgcn_bitop3_b32(word[j], cand[q][j], uint32_t(is0), 0x48);
+          }
+          m[q] = int32_t(e > uint32_t(m[q]) ? e : uint32_t(m[q]));
+          acc[q] = (acc[q] << 1) + is0;
         }
-        d[q] = z + (int32_t(n1) & is1);
-        acc[q] = (acc[q] << 1) + is1;
       }
     }
     const uint32_t oy = uint32_t(y0) + y, ox = uint32_t(c0) + x;
@@ -184,10 +208,14 @@ __device__ __forceinline__ void median_tile(const uint8_t *__restrict__ fsrc, ui
 #pragma unroll
       for (int q = 0; q < NPX; ++q)
         if (ox + uint32_t(q) < a.out_x0 + a.out_w) {
-          if constexpr (COHERENT) __hip_atomic_store(o + q, uint8_t(-acc[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else o[q] = uint8_t(-acc[q]);
+          if constexpr (COHERENT) __hip_atomic_store(o + q, uint8_t(255 + acc[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else o[q] = uint8_t(255 + acc[q]);
         }
     }
+    // the next item, THREADS further on
+    y += uint32_t(S::THREADS) / TWP;
+    x += uint32_t(NPX) * (uint32_t(S::THREADS) % TWP);
+    if (x >= uint32_t(S::TW)) x -= uint32_t(S::TW), ++y;
   }
   if constexpr (COHERENT) __builtin_amdgcn_s_waitcnt(0);  // every store of the tile has left this wave (vmcnt 0)
 }

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def _median_gpu(ctx, imgs, k):
+def _median_gpu(ctx, imgs, k, algo=0):
+    ctx.set_tuning("median_algo", algo)
     src = torch.from_numpy(np.stack(imgs)).cuda()
     n, h, w = src.shape
     dst = torch.full_like(src, 77)
@@ -31,6 +32,46 @@ def test_median_matches_oracle(k, w, h):
         got = _median_gpu(ctx, imgs, k)
     for g, img in zip(got, imgs):
         assert np.array_equal(g, oracle.median_u8(img, k))
+
+
+@pytest.mark.parametrize("k", [9, 11])
+@pytest.mark.parametrize("w,h", [(752, 480), (97, 131), (256, 32), (257, 33), (300, 70), (5, 3), (1, 1), (1, 40), (40, 1),
+                                 (1037, 45)])
+def test_bit_sliced_median_matches_oracle(k, w, h):
+    """d2pc_median_bs.hip (32 pixels per thread, one bit each) forced onto sizes the library would give to the
+    per-pixel kernel: tiles cut by the right and bottom edges, images smaller than the window, ties."""
+    rng = np.random.default_rng(w * 1000 + h + k)
+    imgs = [rng.integers(0, 256, size=(h, w)).astype(np.uint8),
+            (rng.integers(0, 4, size=(h, w)) * 85).astype(np.uint8),
+            np.tile(np.arange(w, dtype=np.uint8), (h, 1))]
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        got = _median_gpu(ctx, imgs, k, algo=2)
+        again = _median_gpu(ctx, imgs, k, algo=1)
+    for g, a, img in zip(got, again, imgs):
+        want = oracle.median_u8(img, k)
+        assert np.array_equal(g, want)
+        assert np.array_equal(a, want)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_median_algorithms_on_strided_rows_and_roi(algo):
+    """Row strides larger than the width, source and destination strides different, ROI-only output."""
+    rng = np.random.default_rng(77 + algo)
+    n, h, w, sp, dp, border = 3, 150, 333, 352, 340, 21
+    src = torch.from_numpy(rng.integers(0, 256, size=(n, h, sp)).astype(np.uint8)).cuda()
+    dst = torch.full((n, h, dp), 77, dtype=torch.uint8, device="cuda")
+    with d2pc.Context(q=d2pc.make_q(), border=border) as ctx:
+        ctx.set_tuning("median_algo", algo)
+        ctx.median_roi_device(src.data_ptr(), w, h, sp, sp * h, n, dst.data_ptr(), dp, dp * h, 11,
+                              torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    got, imgs = dst.cpu().numpy(), src.cpu().numpy()[:, :, :w]
+    inside = np.zeros((h, dp), dtype=bool)
+    inside[border:h - border, border:w - border] = True
+    for g, img in zip(got, imgs):
+        want = oracle.median_u8(np.ascontiguousarray(img), 11)
+        assert np.array_equal(g[:, :w][inside[:, :w]], want[inside[:, :w]])
+        assert np.all(g[~inside] == 77), "pixels outside the ROI must not be written"
 
 
 @pytest.mark.parametrize("k", [3, 11])
@@ -62,10 +103,12 @@ def test_median_4k_batch_and_constant_images():
     a = rng.integers(0, 256, size=(2160, 3840)).astype(np.uint8)
     b = np.full((2160, 3840), 200, dtype=np.uint8)
     b[1000:1100, 2000:2100] = 0
+    want = [oracle.median_u8(a, 11), oracle.median_u8(b, 11)]
     with d2pc.Context(q=d2pc.make_q()) as ctx:
-        got = _median_gpu(ctx, [a, b], 11)
-    assert np.array_equal(got[0], oracle.median_u8(a, 11))
-    assert np.array_equal(got[1], oracle.median_u8(b, 11))
+        for algo in (0, 1, 2):  # 0: the library's choice (bit-sliced at this size)
+            got = _median_gpu(ctx, [a, b], 11, algo)
+            assert np.array_equal(got[0], want[0]), algo
+            assert np.array_equal(got[1], want[1]), algo
 
 
 def test_median_rejects_bad_arguments():

@@ -29,6 +29,17 @@ for (w, h, n) in ((752, 480, 64), (1920, 1080, 16), (3840, 2160, 16)):
     ctx = d2pc.Context(q=q)
     raw = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device="cuda")
     b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8)
+    for algo in (1, 2):  # per-pixel select, bit-sliced (k = 9, 11)
+        try:
+            ctx.set_tuning("median_algo", algo)
+        except Exception:  # a library built before the bit-sliced kernel
+            break
+        us = t(lambda: ctx.median_device(raw.data_ptr(), w, h, w, w * h, n, b.disp.data_ptr(), w, w * h, 11, s))
+        print(f"{w}x{h} x{n}: median11 algo {algo} {us:8.1f} us  = {us/n:7.2f} us/frame  {n*w*h/us:9.1f} Mpix/s", flush=True)
+    try:
+        ctx.set_tuning("median_algo", 0)
+    except Exception:
+        pass
     for k in (3, 11):
         us = t(lambda: ctx.median_device(raw.data_ptr(), w, h, w, w * h, n, b.disp.data_ptr(), w, w * h, k, s))
         print(f"{w}x{h} x{n}: median{k:2d} {us:8.1f} us  = {us/n:7.2f} us/frame  {n*w*h/us:9.1f} Mpix/s", flush=True)
