@@ -458,7 +458,9 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
  * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
  * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
- * "callback_fused" (0/1: the heterogeneous persistent kernel there; default 0). */
+ * "callback_fused" (0/1: the heterogeneous persistent kernel there; default 0),
+ * "median_algo" (0 = choose per launch, 1 = one pixel per thread, 2 = 32 pixels per thread bit-sliced -- 9x9 and
+ * 11x11 only, otherwise 1 is taken; the two give identical bytes). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

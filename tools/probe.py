@@ -53,9 +53,11 @@ def main():
     ap.add_argument("--scale", type=float, default=None)
     ap.add_argument("--tune", action="append", default=[], help="key=value for d2pc_set_tuning (repeatable)")
     a = ap.parse_args()
-    if WORKLOADS[a.workload][0] == "median":   # k_median_u8<11> over the inset ROI, 16 x 4K (cpp:55-57)
+    if WORKLOADS[a.workload][0] == "median":   # the 11 x 11 median over the inset ROI, 16 x 4K (cpp:55-57); --tune median_algo=1|2 picks the kernel
         _, F, W, H, border, *_ = WORKLOADS[a.workload]
         ctx = d2pc.Context(q=d2pc.make_q(), border=border)
+        for kv in a.tune:
+            ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
         raw = torch.randint(0, 256, (F, H, W), dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(raw)
         s = torch.cuda.current_stream().cuda_stream
