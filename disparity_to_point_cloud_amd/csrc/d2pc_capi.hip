@@ -87,8 +87,10 @@ struct d2pc_ctx {
   uint32_t *d_counts = nullptr;
   uint32_t *h_counts = nullptr;  // pinned
   // d2pc_process_mono_device: two internal streams + scratch for the filtered frames
-  int cb_fused = 0;              // median 11 + PARITY reprojection of 8-bit batches in ONE persistent kernel
-                                 // (k_callback_fused): correct, but slower than the two launches -- off; see DESIGN section 9
+  int cb_fused = 2;              // d2pc_process_mono_device, median + PARITY reprojection in one kernel: 0 never; 2 tile by
+                                 // tile (k_callback_bs: bit-sliced median, the tile's points from LDS) when the launch is
+                                 // large enough for the bit-sliced filter; 1 the persistent two-role kernel
+                                 // (k_callback_fused): correct, but slower than two launches -- DESIGN section 9
   int cb_chunks = 1;             // pipeline chunks per call (<= 1: everything in order on the caller's stream;
                                  // overlapping did not pay reliably: profiles/r02_callback_overlap.txt)
   hipStream_t cb_stream_m = nullptr, cb_stream_r = nullptr;
@@ -754,7 +756,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "callback_chunks") && value >= 0 && value <= 64) ctx->cb_chunks = value;
-  else if (!strcmp(key, "callback_fused") && (value == 0 || value == 1)) ctx->cb_fused = value;
+  else if (!strcmp(key, "callback_fused") && value >= 0 && value <= 2) ctx->cb_fused = value;
   else if (!strcmp(key, "median_algo") && value >= 0 && value <= 2) ctx->median_algo = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
@@ -1132,7 +1134,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
   }
   // The reference's own constants (11 x 11, 8-bit, everything published) on a batch: one persistent kernel in which
   // the filter and the reprojection run side by side on every CU (k_callback_fused)
-  if (ctx->cb_fused && median && median_ksize == 11 && !bridge16 && !compact && !d_idx && n_frames >= 2) {
+  if (ctx->cb_fused == 1 && median && median_ksize == 11 && !bridge16 && !compact && !d_idx && n_frames >= 2) {
     Geom g;
     if ((st = make_geom(ctx, D2PC_DTYPE_U8, scale, width, height, kpitch, kframe, n_frames, out_frame_stride, 8, &g)) != D2PC_OK)
       return st;
@@ -1214,6 +1216,24 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
       m.src_frame_stride = kin_frame;
       m.dst_frame_stride = kframe;
       median_roi_only(m, gin, height);
+      if (ctx->cb_fused == 2 && !compact && !overlap && median_uses_bs(m, median_ksize)) {
+        // filter and points tile by tile in one kernel; the filtered frames never reach memory
+        Geom g;
+        if ((st = make_geom(ctx, D2PC_DTYPE_U8, scale, width, height, kin_pitch, kin_frame, nf, out_frame_stride, pxt, &g)) != D2PC_OK)
+          return st;
+        LaunchArgs a;
+        a.out_points = static_cast<uint8_t *>(d_out) + size_t(f0) * out_frame_stride * 16;
+        a.out_index = d_idx ? d_idx + size_t(f0) * out_frame_stride : nullptr;
+        a.counts = d_counts ? d_counts + f0 : nullptr;
+        a.dtype = D2PC_DTYPE_U8;
+        a.stream = sr;
+        a.geom = g;
+        memcpy(a.q.q, ctx->q, sizeof a.q.q);
+        a.qs = ctx->qs;
+        a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
+        D2PC_HIP(ctx, launch_callback_bs(a, m, kin, median_ksize));
+        continue;
+      }
       uint8_t *dst = static_cast<uint8_t *>(ctx->d_cb_med) + size_t(f0) * kframe;
       D2PC_HIP(ctx, launch_median(kin, dst, m, median_ksize, sm));
       kin = dst;

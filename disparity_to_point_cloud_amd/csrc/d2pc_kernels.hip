@@ -21,6 +21,7 @@
 //    so the output order equals the CPU loop's row-major order bit-for-bit.
 #include "d2pc_device.hpp"
 #include "d2pc_launch.hpp"
+#include "d2pc_median_bs_tile.hpp"
 #include "d2pc_median_tile.hpp"
 
 namespace d2pc {
@@ -521,6 +522,92 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_callback_fused(
       }
     }
   }
+}
+
+// --------------------------------------------------------------------------
+// K1g: the callback body TILE BY TILE -- bit-sliced k x k median of a 256 x 32 tile of the inset ROI
+// (d2pc_median_bs_tile.hpp, cpp:55-57) and, from the filtered bytes still in LDS, the tile's points
+// (cpp:60-85, PARITY).  No hand-off between blocks and no filtered image in memory: the VALU-bound filter
+// and the store stream of the reprojection overlap because the chip's ~770 resident blocks are at
+// different stages at any time.  (k_callback_fused above tried the same overlap with two roles and
+// cross-block hand-offs, and lost.)
+//  * 8-bit input has 256 disparities, and with stereoRectify's Q (QK_STEREO) W = a*d + b does not depend on
+//    the pixel: every block evaluates 1/W and Z once per byte value (one division per THREAD) into LDS, and a
+//    pixel costs two fp64 additions, two multiplications and two casts -- the same operations on the same
+//    operands as reproject(), so the points are bit-identical to k_reproject_pack's.
+//  * a wave stores 64 consecutive points per instruction (1 KiB), like the PARITY kernel.
+// --------------------------------------------------------------------------
+template <int KS, int QK>
+__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_callback_bs(
+    const uint8_t *__restrict__ src, float4 *__restrict__ out, uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
+    const MedianArgs ma, const Geom g, const QArg<QK> Q) {
+  using S = MedianBsShape<KS>;
+  static_assert(S::THREADS == 256, "one thread per byte value fills the table");
+  __shared__ __attribute__((aligned(16))) uint32_t s_w[S::W_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_raw[S::RAW_WORDS];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t b = blockIdx.x;
+  const uint32_t f = b / (ma.tiles_x * ma.tiles_y);
+  b -= f * ma.tiles_x * ma.tiles_y;
+  const uint32_t ty = b / ma.tiles_x, tx = b - ty * ma.tiles_x;
+  const uint32_t x0 = ma.out_x0 + tx * uint32_t(S::TW), y0 = ma.out_y0 + ty * uint32_t(S::TH);  // first output pixel
+  median_bs_tile<KS>(src + uint64_t(f) * ma.src_frame_stride, ma, int(x0), int(y0), s_w, s_raw, tid);
+
+  double *lut_iw = reinterpret_cast<double *>(s_raw);              // [256]
+  float *lut_z = reinterpret_cast<float *>(s_raw) + 2 * 256;       // [256]
+  static_assert(S::RAW_WORDS >= 3 * 256, "the table fits where the staged rows were");
+  if constexpr (QK == QK_STEREO) {
+    const float d = __fmul_rn(float(tid), g.scale);  // cpp:61, as load_disparity<DT_U8>
+    const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
+    const double iw = 1.0 / fma(Q.s.a, double(dsel), Q.s.b);
+    lut_iw[tid] = iw;
+    lut_z[tid] = big_z_rule(d, float(Q.s.f * iw));
+    __syncthreads();
+  }
+  const uint8_t *ob = reinterpret_cast<const uint8_t *>(s_w);
+  float4 *fout = out + uint64_t(f) * g.out_frame_stride;
+  uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
+  const uint32_t x_end = ma.out_x0 + ma.out_w, y_end = ma.out_y0 + ma.out_h;
+  // a lane's four columns do not change from row to row: (u + cx) is formed once (QK_STEREO)
+  double xs[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    xs[q] = 0.0;
+    if constexpr (QK == QK_STEREO) xs[q] = double(x0 + 64u * uint32_t(q) + lane) + Q.s.cx;
+  }
+#pragma unroll 1
+  for (uint32_t r = wave; r < uint32_t(S::TH); r += uint32_t(S::THREADS / 64)) {  // a wave takes every fourth row
+    const uint32_t y = y0 + r;
+    if (y >= y_end) break;
+    const uint32_t row_point = (y - g.border) * g.roi_w - g.border;  // + x = the point's index (wraps for x < border: never used)
+    uint32_t raw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[q] = ob[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
+    double ys = 0.0;
+    if constexpr (QK == QK_STEREO) ys = double(y) + Q.s.cy;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t x = x0 + 64u * uint32_t(q) + lane;
+      float X, Y, Z;
+      if constexpr (QK == QK_STEREO) {
+        const double iw = lut_iw[raw[q]];
+        X = float(xs[q] * iw);
+        Y = float(ys * iw);
+        Z = lut_z[raw[q]];
+      } else {
+        reproject(Q, x, y, __fmul_rn(float(raw[q]), g.scale), X, Y, Z);
+      }
+#ifdef D2PC_CB_BS_DIAG_NOSTORE  // (timing diagnosis: the points are computed and dropped)
+      if (x < x_end && X == 1.25f && Y == 2.5f && Z == 7.75f) {
+#else
+      if (x < x_end) {
+#endif
+        store_point<D2PC_STORE_NT != 0>(fout, row_point + x, X, Y, Z);
+        if (fidx) store_index(fidx, row_point + x, y * g.width + x);
+      }
+    }
+  }
+  if (counts && b == 0 && tid == 0) counts[f] = g.roi_n;
 }
 
 // --------------------------------------------------------------------------
@@ -1449,6 +1536,32 @@ hipError_t launch_callback_fused(const LaunchArgs &a, MedianArgs m, const void *
     hipLaunchKernelGGL((k_callback_fused<11, QK_GENERAL, 8>), dim3(blocks), dim3(S::THREADS), 0, a.stream,
                        static_cast<const uint8_t *>(src), static_cast<uint8_t *>(med), static_cast<float4 *>(a.out_points),
                        a.counts, static_cast<FusedSync *>(sync), m, a.geom, make_qarg<QK_GENERAL>(a), r_per_frame, spin_ticks);
+  return hipGetLastError();
+}
+
+hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src, int ksize) {
+  if ((ksize != 9 && ksize != 11) || m.out_w == 0 || m.out_h == 0) return hipErrorInvalidValue;
+  if (m.out_x0 != a.geom.border || m.out_y0 != a.geom.border || m.out_w != a.geom.roi_w ||
+      uint64_t(m.out_w) * m.out_h != a.geom.roi_n)
+    return hipErrorInvalidValue;  // the filter's output rectangle must be the reprojection's ROI
+  using S = MedianBsShape<11>;  // the tile shape does not depend on k
+  m.tiles_x = (m.out_w + S::TW - 1) / S::TW;
+  m.tiles_y = (m.out_h + S::TH - 1) / S::TH;
+  const uint64_t blocks = uint64_t(m.tiles_x) * m.tiles_y * m.n_frames;
+  if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  const uint8_t *s8 = static_cast<const uint8_t *>(src);
+  float4 *o = static_cast<float4 *>(a.out_points);
+#define D2PC_CB_BS(KS, QK)                                                                                              \
+  hipLaunchKernelGGL((k_callback_bs<KS, QK>), dim3(uint32_t(blocks)), dim3(S::THREADS), 0, a.stream, s8, o, a.out_index, \
+                     a.counts, m, a.geom, make_qarg<QK>(a))
+  if (ksize == 11) {
+    if (a.q_kind == QK_STEREO) D2PC_CB_BS(11, QK_STEREO);
+    else D2PC_CB_BS(11, QK_GENERAL);
+  } else {
+    if (a.q_kind == QK_STEREO) D2PC_CB_BS(9, QK_STEREO);
+    else D2PC_CB_BS(9, QK_GENERAL);
+  }
+#undef D2PC_CB_BS
   return hipGetLastError();
 }
 

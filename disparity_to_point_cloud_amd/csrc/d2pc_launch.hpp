@@ -46,6 +46,7 @@ struct MedianArgs {
 };
 bool median_ksize_supported(int k);
 uint64_t median_bs_tiles(const MedianArgs &a);  // a.out_* resolved
+bool median_uses_bs(const MedianArgs &a, int ksize);  // a.out_* resolved: would launch_median take the bit-sliced kernel?
 hipError_t launch_median_bs(const void *src, void *dst, const MedianArgs &a, int ksize, hipStream_t stream);
 hipError_t launch_median(const void *src, void *dst, const MedianArgs &a, int ksize, hipStream_t stream);
 // cv_bridge mono16 -> mono8 (d2pc_median.hip); strides in bytes, src rows hold uint16
@@ -94,6 +95,10 @@ hipError_t launch_parity(const LaunchArgs &a);
 size_t fused_sync_bytes(uint32_t n_frames);
 hipError_t launch_callback_fused(const LaunchArgs &a, MedianArgs m, const void *src, void *med, int ksize, void *sync,
                                  uint32_t blocks, uint32_t spin_ticks);
+// tile-fused callback body (bit-sliced k x k median, k = 9 or 11, + PARITY reprojection of the tile from LDS;
+// k_callback_bs): `m` carries the filter's geometry with the output rectangle = the ROI of a.geom; a.out_points,
+// a.out_index (nullable), a.counts (nullable), a.q*, a.stream as in launch_parity
+hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src, int ksize);
 hipError_t launch_compact(const LaunchArgs &a);
 
 }  // namespace d2pc

@@ -113,6 +113,11 @@ hipError_t launch_k(const uint8_t *s, uint8_t *d, MedianArgs a, hipStream_t stre
 // tiles, 7 us) the per-pixel kernel's 18 x 64 tiles spread better.
 constexpr uint64_t kBsMinTiles = 448;
 
+bool median_uses_bs(const MedianArgs &a, int ksize) {
+  return (ksize == 9 || ksize == 11) && a.out_w != 0 && a.out_h != 0 &&
+         (a.algo == 2 || (a.algo == 0 && median_bs_tiles(a) >= kBsMinTiles));
+}
+
 hipError_t launch_median(const void *src, void *dst, const MedianArgs &args, int ksize, hipStream_t stream) {
   const uint8_t *s = static_cast<const uint8_t *>(src);
   uint8_t *d = static_cast<uint8_t *>(dst);
@@ -123,8 +128,7 @@ hipError_t launch_median(const void *src, void *dst, const MedianArgs &args, int
     a.out_h = a.height;
   }
   if (a.out_x0 + a.out_w > a.width || a.out_y0 + a.out_h > a.height) return hipErrorInvalidValue;
-  if ((ksize == 9 || ksize == 11) && (a.algo == 2 || (a.algo == 0 && median_bs_tiles(a) >= kBsMinTiles)))
-    return launch_median_bs(src, dst, a, ksize, stream);
+  if (median_uses_bs(a, ksize)) return launch_median_bs(src, dst, a, ksize, stream);
   switch (ksize) {
     case 3: return launch_k<3>(s, d, a, stream);
     case 5: return launch_k<5>(s, d, a, stream);

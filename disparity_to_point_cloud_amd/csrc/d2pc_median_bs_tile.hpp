@@ -1,0 +1,325 @@
+// d2pc_median_bs_tile.hpp -- the tile body of d2pc_median_bs.hip, shared with the tile-fused callback kernel
+// (k_callback_bs in d2pc_kernels.hip).
+//
+// d2pc_median_bs.hip -- k x k median of an 8-bit image on gfx950, BIT-SLICED ACROSS PIXELS: the second
+// device form of cv::medianBlur(img, out, 11) at reference src/disparity_to_point_cloud.cpp:55-57
+// (SURVEY.md section 8(f) #1), used for large launches; d2pc_median.hip (one pixel per thread) serves the rest.
+//
+// Why a second kernel.  tools/valu_rate.hip: on gfx950 the bitwise VALU instructions (v_and, v_xor,
+// v_bitop3) issue every 2 cycles per SIMD, v_bcnt_u32_b32 and most other integer instructions every 4.  The
+// per-pixel radix select spends a third of its instructions and half of its issue cycles on popcounts.
+// Here a thread owns 32 output pixels of one row, ONE BIT PER PIXEL in every register, and the whole select
+// is v_and / v_bitop3:
+//   * cand[dy][dx] (k*k words): bit j set <=> window position (dy, dx) of pixel j is still a candidate
+//   * per bit plane, MSB first: M = cand & W(dy, dx) marks the candidates whose bit is 1; the k*k words M are
+//     summed PER BIT POSITION by a carry-save adder tree (a full adder = 2 v_bitop3 on 3 words) into an 8-bit
+//     number held as 8 words; the rank test, the rank update and the candidate update cand &= W ^ is0 are
+//     bitwise as well.  Per pixel and plane: k*k * (1 + ~2 + 1) / 32 = 15 two-cycle instructions for 11 x 11,
+//     against 6 * 3 + 5 = 23 instructions (6 of them four-cycle) per pixel.
+//   * W(dy, dx) is the bit plane of the pixels (x_j + dx, y + dy).  A thread's pixels are S = 8 COLUMNS APART,
+//     x_j = X0 + 8 j + t (t = 0..7), so that shifting the window by dx moves to ANOTHER WORD instead of shifting
+//     bits: with W_u[bit j] = pixel X0 + 8 j + u, thread t reads the words u = t .. t + k - 1 of a row, and
+//     W_{u+8} = W_u >> 1 (plus one pixel of the next tile).  18 words per row and plane serve 256 pixels.
+//   * LDS: W[plane][row][24 dwords] (18 used; the stride makes the ds_read_b64 of a 32-lane group -- 4 threads
+//     x 8 rows -- hit 64 different banks).  Even and odd t run in different waves: a thread reads the six
+//     aligned pairs from word (t & ~1) on and uses words [par .. par + 11) of them, so `par` must be uniform.
+//   * both passes over the window (count, then candidate update) read W from LDS: 2 * 66 ds_read_b64 per
+//     plane and thread; the k*k candidate words stay in registers (121 + ~40: two or three waves per SIMD).
+//
+// The result is bit-identical to d2pc_median.hip and to the oracle (tests/test_median_gpu.py runs both).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "d2pc_launch.hpp"
+
+namespace d2pc {
+
+template <int KS>
+struct MedianBsShape {
+  static constexpr int R = KS / 2;
+  static constexpr int S = 8;                     // column distance of a thread's pixels
+  static constexpr int TW = 32 * S;               // tile width (output pixels)
+  static constexpr int TH = 32;                   // tile height
+  static constexpr int THREADS = S * TH;          // one thread per (t, row)
+  static constexpr int IN_ROWS = TH + KS - 1;
+  static constexpr int NW = S + KS - 1;           // words W_0 .. W_{NW-1} per plane and row
+  static constexpr int ROW_STRIDE = 24;           // dwords; 24 r mod 64 takes 8 different multiples of 8 for 8 rows
+  static constexpr int PLANE_STRIDE = IN_ROWS * ROW_STRIDE;
+  static constexpr int W_WORDS = 8 * PLANE_STRIDE;
+  static constexpr int NREAD = (KS + 2) / 2;      // aligned word pairs that cover words [par, par + KS)
+  static constexpr int RAW_STRIDE = 272;          // bytes per staged input row (>= TW + 2 * 8 = every byte the gather touches)
+  static constexpr int RAW_WORDS = IN_ROWS * RAW_STRIDE / 4;
+  static constexpr int D0 = KS * KS - (KS * KS / 2 + 1);  // candidates above the median at the start
+  static_assert(KS % 2 == 1 && KS >= 3 && KS <= 11, "k*k < 128: the rank arithmetic is 7 + 1 bits");
+  static_assert(2 * NREAD + 6 <= ROW_STRIDE && NW <= ROW_STRIDE, "reads stay inside the row's slot");
+  static_assert(RAW_WORDS * 4 >= 8 * THREADS * 4, "the staged rows' space later holds 8 result words per thread");
+  static constexpr int OUT_STRIDE = TW + 16;      // bytes per staged output row: rows 4 banks apart (byte stores of 8 rows x 2 dwords)
+  static_assert(W_WORDS * 4 >= OUT_STRIDE * TH, "W's space later holds the tile's output bytes");
+};
+
+namespace bs {
+
+template <uint32_t TABLE>  // bit (4a + 2b + c) of TABLE is the result for the input bits (a, b, c)
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, TABLE);
+}
+
+// 32 pixels (px[k] = pixels 4k .. 4k+3, one per byte) <-> eight plane words (bit j of plane[b] = bit b of pixel j).
+// Both steps are transposes (8 x 8 bits inside a register pair, 4 x 4 bytes across four registers), hence
+// their own inverses: to_planes runs them one way, to_pixels the other.
+__device__ __forceinline__ void bit_transpose_8x8(uint32_t &lo, uint32_t &hi) {
+  uint32_t t;
+  t = (lo ^ (lo >> 7)) & 0x00aa00aau, lo ^= t ^ (t << 7);
+  t = (hi ^ (hi >> 7)) & 0x00aa00aau, hi ^= t ^ (t << 7);
+  t = (lo ^ (lo >> 14)) & 0x0000ccccu, lo ^= t ^ (t << 14);
+  t = (hi ^ (hi >> 14)) & 0x0000ccccu, hi ^= t ^ (t << 14);
+  t = (lo ^ ((lo >> 28) | (hi << 4))) & 0xf0f0f0f0u;
+  lo ^= t ^ (t << 28);
+  hi ^= t >> 4;
+}
+__device__ __forceinline__ void byte_transpose_4x4(const uint32_t b0, const uint32_t b1, const uint32_t b2, const uint32_t b3,
+                                                   uint32_t (&o)[4]) {
+  const uint32_t a0 = __builtin_amdgcn_perm(b1, b0, 0x05010400u), a1 = __builtin_amdgcn_perm(b1, b0, 0x07030602u);
+  const uint32_t a2 = __builtin_amdgcn_perm(b3, b2, 0x05010400u), a3 = __builtin_amdgcn_perm(b3, b2, 0x07030602u);
+  o[0] = __builtin_amdgcn_perm(a2, a0, 0x05040100u);
+  o[1] = __builtin_amdgcn_perm(a2, a0, 0x07060302u);
+  o[2] = __builtin_amdgcn_perm(a3, a1, 0x05040100u);
+  o[3] = __builtin_amdgcn_perm(a3, a1, 0x07060302u);
+}
+__device__ __forceinline__ void to_planes(uint32_t (&px)[8], uint32_t (&plane)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) bit_transpose_8x8(px[j], px[j + 1]);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint32_t o[4];
+    byte_transpose_4x4(px[h], px[2 + h], px[4 + h], px[6 + h], o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) plane[4 * h + i] = o[i];
+  }
+}
+__device__ __forceinline__ void to_pixels(const uint32_t (&plane)[8], uint32_t (&px)[8]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint32_t o[4];
+    byte_transpose_4x4(plane[4 * h], plane[4 * h + 1], plane[4 * h + 2], plane[4 * h + 3], o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) px[2 * i + h] = o[i];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) bit_transpose_8x8(px[j], px[j + 1]);
+}
+
+// Carry-save counter: per bit position, how many of the words added so far had that bit set.  Level L holds
+// up to two pending words of weight 2^L; a third makes a full adder whose carry moves one level up.  Every
+// n[] is a compile-time constant once the loops around add() are unrolled, so this is straight-line code.
+struct Csa {
+  uint32_t a[8], b[8];
+  int n[8];
+};
+template <int L>
+__device__ __forceinline__ void csa_add(Csa &c, const uint32_t x) {
+  if constexpr (L < 8) {
+    if (c.n[L] == 0) {
+      c.a[L] = x, c.n[L] = 1;
+    } else if (c.n[L] == 1) {
+      c.b[L] = x, c.n[L] = 2;
+    } else {
+      const uint32_t s = bitop3<0x96>(c.a[L], c.b[L], x);   // a ^ b ^ x
+      const uint32_t cy = bitop3<0xe8>(c.a[L], c.b[L], x);  // majority
+      c.a[L] = s, c.n[L] = 1;
+      csa_add<L + 1>(c, cy);
+    }
+  }
+}
+// the pending words of all levels -> the binary digits s[0..7] of the count (count < 256)
+__device__ __forceinline__ void csa_finish(Csa &c, uint32_t (&s)[8]) {
+  bool have_carry = false;
+  uint32_t carry = 0;
+#pragma unroll
+  for (int L = 0; L < 8; ++L) {
+    const int inputs = c.n[L] + (have_carry ? 1 : 0);
+    if (inputs == 0) {
+      s[L] = 0, have_carry = false;
+    } else if (inputs == 1) {
+      s[L] = have_carry ? carry : c.a[L], have_carry = false;
+    } else if (inputs == 2) {
+      const uint32_t x = c.a[L], y = have_carry ? carry : c.b[L];
+      s[L] = x ^ y, carry = x & y, have_carry = true;
+    } else {
+      s[L] = bitop3<0x96>(c.a[L], c.b[L], carry);
+      carry = bitop3<0xe8>(c.a[L], c.b[L], carry), have_carry = true;
+    }
+  }
+}
+
+// One ds_read_b64 (256 B/clk/CU).  Volatile: left to itself the compiler drops the half of the first or last
+// pair that the parity does not use and re-pairs the rest as ds_read2_b32, which runs at half that rate.
+__device__ __forceinline__ uint2 ld_pair(const uint32_t *p) {
+  typedef const volatile __attribute__((address_space(3))) uint64_t *lds_u64;  // (volatile hides the address space)
+  const uint64_t q = *(lds_u64)(p);
+  return make_uint2(uint32_t(q), uint32_t(q >> 32));
+}
+
+// The select of one thread: 32 pixels of output row `row`, columns 8 j + t.  `w_row` points at word (t & ~1)
+// of plane 0, input row `row` (the window's first row).  Returns nothing: the median's bit planes go to
+// bits_out[plane * THREADS].
+template <int KS>
+__device__ __forceinline__ void ld_row(const uint32_t *p, uint32_t (&w)[2 * MedianBsShape<KS>::NREAD]) {
+#pragma unroll
+  for (int i = 0; i < MedianBsShape<KS>::NREAD; ++i) {
+    const uint2 v = ld_pair(p + 2 * i);
+    w[2 * i] = v.x, w[2 * i + 1] = v.y;
+  }
+}
+
+template <int KS, int PAR>
+__device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint32_t *__restrict__ bits_out) {
+  using S = MedianBsShape<KS>;
+  constexpr int NWORD = 2 * S::NREAD;
+  uint32_t cand[KS][KS];
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = 0xffffffffu;
+  // mm = 127 - d as seven words (d = candidates above the median): count + mm >= 128  <=>  count > d  <=>
+  // the median's bit is 1; otherwise d becomes d - count, i.e. mm becomes the sum's low seven digits.
+  uint32_t mm[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) mm[k] = ((127 - S::D0) >> k) & 1 ? 0xffffffffu : 0u;
+#pragma unroll 1
+  for (int pl = 7; pl >= 0; --pl) {
+    const uint32_t *wp = w_row + pl * S::PLANE_STRIDE;
+    Csa c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.a[k] = k < 7 ? mm[k] : 0u, c.b[k] = 0u, c.n[k] = k < 7 ? 1 : 0;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      uint32_t w[NWORD];
+      ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, cand[dy][dx] & w[dx + PAR]);
+    }
+    uint32_t s[8];
+    csa_finish(c, s);
+    bits_out[pl * S::THREADS] = s[7];
+    if (pl == 0) break;  // the candidates are not needed any more
+    const uint32_t is0 = ~s[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) mm[k] = bitop3<0xca>(is0, s[k], mm[k]);  // is0 ? s : mm
+    // second pass: the candidate update.  (Loading each row's words one visit ahead, which costs the last
+    // spare registers, changed nothing: with three waves per SIMD the loop is bound by instruction issue,
+    // not by the LDS round trip -- a build without any LDS read in this loop takes the same time.)
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      uint32_t w[NWORD];
+      ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = bitop3<0x48>(w[dx + PAR], cand[dy][dx], is0);  // cand & (w ^ is0)
+    }
+  }
+}
+
+}  // namespace bs
+
+// Stages 1-4 of one 256 x 32 tile whose first output pixel is (x0, y0) of frame `fsrc`: afterwards (the function
+// ends with the block barrier) the tile's filtered bytes lie in s_w, read as bytes, OUT_STRIDE per row, and
+// s_raw is free.  Called by all THREADS threads of the block.
+template <int KS>
+__device__ __forceinline__ void median_bs_tile(const uint8_t *__restrict__ fsrc, const MedianArgs &a, const int x0, const int y0,
+                                               uint32_t (&s_w)[MedianBsShape<KS>::W_WORDS],
+                                               uint32_t (&s_raw)[MedianBsShape<KS>::RAW_WORDS], const uint32_t tid) {
+  using S = MedianBsShape<KS>;
+  constexpr int R = S::R;
+  // ---- 1. the tile's input rows (+ halo), replicated at the image edges, as bytes in LDS ------------
+  // 16-byte runs, all of a thread's loads issued before the first LDS store (a loop with the edge test
+  // inside serialises a dozen global round trips per block: a third of the kernel's time)
+  {
+    constexpr int RUNS = S::RAW_STRIDE / 16, TOTAL = S::IN_ROWS * RUNS, PER_THREAD = (TOTAL + S::THREADS - 1) / S::THREADS;
+    const bool interior = x0 - R >= 0 && x0 - R + S::RAW_STRIDE <= int(a.width);  // block-uniform
+    uint4 v[PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+      const uint32_t c = tid + uint32_t(k * S::THREADS);
+      const uint32_t r = c / uint32_t(RUNS), i16 = 16u * (c - r * uint32_t(RUNS));
+      int iy = y0 - R + int(r);
+      iy = iy < 0 ? 0 : iy >= int(a.height) ? int(a.height) - 1 : iy;  // (also keeps the rows of c >= TOTAL in bounds)
+      const uint8_t *row = fsrc + uint64_t(iy) * a.src_row_stride;
+      const int x = x0 - R + int(i16);
+      if (interior) {
+        __builtin_memcpy(&v[k], row + x, 16);
+      } else {
+        uint32_t d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          d[q] = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int ix = x + 4 * q + e;
+            ix = ix < 0 ? 0 : ix >= int(a.width) ? int(a.width) - 1 : ix;
+            d[q] |= uint32_t(row[ix]) << (8 * e);
+          }
+        }
+        v[k] = make_uint4(d[0], d[1], d[2], d[3]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+      const uint32_t c = tid + uint32_t(k * S::THREADS);
+      if (c < uint32_t(TOTAL)) reinterpret_cast<uint4 *>(s_raw)[c] = v[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. plane words: item (row r, u) gathers the pixels 8 j + u of the row --------------------------
+  {
+    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s_raw);
+    for (uint32_t item = tid; item < uint32_t(S::IN_ROWS * S::S); item += uint32_t(S::THREADS)) {
+      const uint32_t r = item >> 3, u = item & 7u;
+      const uint8_t *rp = raw + r * uint32_t(S::RAW_STRIDE) + u;
+      uint32_t px[8], plane[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        px[k] = uint32_t(rp[32 * k]) | (uint32_t(rp[32 * k + 8]) << 8) | (uint32_t(rp[32 * k + 16]) << 16) |
+                (uint32_t(rp[32 * k + 24]) << 24);
+      const uint32_t e1 = rp[256], e2 = rp[264];  // the next tile's first pixels at this u: bit 32 and 33 of the row
+      bs::to_planes(px, plane);
+      uint32_t *wr = s_w + r * uint32_t(S::ROW_STRIDE) + u;
+#pragma unroll
+      for (int pl = 0; pl < 8; ++pl) {
+        const uint32_t hi = ((e1 >> pl) & 1u) | (((e2 >> pl) & 1u) << 1);
+        wr[pl * S::PLANE_STRIDE] = plane[pl];
+        if (u + 8u < uint32_t(S::NW)) wr[pl * S::PLANE_STRIDE + 8] = __builtin_amdgcn_alignbit(hi, plane[pl], 1);
+        if (S::NW > 16 && u + 16u < uint32_t(S::NW)) wr[pl * S::PLANE_STRIDE + 16] = __builtin_amdgcn_alignbit(hi, plane[pl], 2);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. the select: wave = one parity of t, 16 rows; lane = (t >> 1) + 4 * row -----------------------
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  const uint32_t par = wave & 1u, t = 2u * (lane & 3u) + par, row = 16u * (wave >> 1) + (lane >> 2);
+  {
+    const uint32_t *w_row = s_w + row * uint32_t(S::ROW_STRIDE) + (t - par);
+    uint32_t *bits_out = s_raw + tid;  // the staged bytes are no longer needed
+    if (par) bs::select<KS, 1>(w_row, bits_out);
+    else bs::select<KS, 0>(w_row, bits_out);
+  }
+  __syncthreads();  // every wave has finished reading W
+
+  // ---- 4. bit planes -> bytes, staged in W's space, stored in 16-byte runs ---------------------------
+  {
+    uint32_t plane[8], px[8];
+#pragma unroll
+    for (int pl = 0; pl < 8; ++pl) plane[pl] = s_raw[pl * S::THREADS + tid];
+    bs::to_pixels(plane, px);
+    uint8_t *ob = reinterpret_cast<uint8_t *>(s_w) + row * uint32_t(S::OUT_STRIDE) + t;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ob[8 * (4 * k + q)] = uint8_t(px[k] >> (8 * q));
+  }
+  __syncthreads();
+}
+
+}  // namespace d2pc

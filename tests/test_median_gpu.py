@@ -333,3 +333,45 @@ def test_fused_callback_kernel_matches_the_two_launches_and_the_oracle(shape):
         assert len(res[1][f][0]) == len(want)
         assert np.array_equal(res[1][f][0].view(np.uint32), res[0][f][0].view(np.uint32)), f"frame {f}: fused != two launches"
         assert_points_close(res[1][f][0], want, max_ulp=1, rel=1e-5, what=f"fused frame {f}")
+
+
+@pytest.mark.parametrize("general_q", [0, 1])
+@pytest.mark.parametrize("k,shape,border,scale", [(11, (3, 480, 752), 40, 0.125), (11, (2, 131, 203), 7, 0.37),
+                                                  (9, (2, 300, 408), 40, 0.125), (11, (1, 97, 600), 0, 1.0),
+                                                  (11, (2, 1080, 1920), 40, 0.125)])
+def test_tile_fused_callback_kernel_matches_the_two_launches_and_the_oracle(general_q, k, shape, border, scale):
+    """k_callback_bs: the bit-sliced median of a 256 x 32 tile and, from the filtered bytes still in LDS, the tile's
+    points (for stereoRectify's Q through a per-block table of 1/W and Z over the 256 byte values).  Forced onto
+    small and ragged sizes (median_algo 2); must equal the filter launch + reprojection launch bit for bit --
+    points, indices and counts -- and the oracle, for both forms of Q."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    q = d2pc.make_q()
+    n, h, w = shape
+    rng = np.random.default_rng(n * h + w + k)
+    pitch = w + 13
+    imgs = rng.integers(0, 256, size=(n, h, pitch)).astype(np.uint8)
+    src = torch.from_numpy(imgs).cuda()
+    res = {}
+    with d2pc.Context(q=q, border=border) as ctx:
+        ctx.set_tuning("force_general_q", general_q)
+        ctx.set_tuning("median_algo", 2)
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
+        s = torch.cuda.current_stream().cuda_stream
+        for fused in (2, 0):
+            ctx.set_tuning("callback_fused", fused)
+            for _ in range(2):
+                b.points.fill_(0)
+                b.index.fill_(-1)
+                b.counts.fill_(0)
+                ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, pitch, pitch * h, n, k, scale,
+                                        b.points.data_ptr(), b.index.data_ptr(), b.stride, b.counts.data_ptr(), s)
+            torch.cuda.synchronize()
+            res[fused] = (b.points.cpu().numpy().copy(), b.index.cpu().numpy().copy(), b.counts.cpu().numpy().copy())
+        ctx.check_async_error()
+    for a, c in zip(res[2], res[0]):
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), "tile-fused kernel differs from the two launches"
+    pts = res[2][0].reshape(n, -1, 4)
+    for f in range(n):
+        want = oracle.reproject(oracle.median_u8(np.ascontiguousarray(imgs[f, :, :w]), k), q, border=border, scale=scale)
+        assert res[2][2].view(np.uint32)[f] == len(want)
+        assert_points_close(pts[f][:len(want)], want, max_ulp=1, rel=1e-5, what=f"frame {f}")
