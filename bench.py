@@ -434,17 +434,24 @@ def main():
                             generator=torch.Generator(device=dev).manual_seed(0xD2C))
         s3 = torch.cuda.current_stream().cuda_stream
 
-        class _Body:
+        class _Body:  # the entry point a caller uses: d2pc_process_mono_device (k_callback_bs at this size)
             def launch(self):
-                # cpp:55-57 for the pixels cpp:70-76 read: the ROI-only median (d2pc_median_roi_device)
+                c3.process_mono_device(raw.data_ptr(), d2pc.DTYPE_U8, W4K, H4K, W4K, W4K * H4K, a.frames, 11, 0.125,
+                                       b3.points.data_ptr(), None, b3.stride, b3.counts.data_ptr(), s3)
+
+        class _TwoLaunches:  # the same work as two kernels: cpp:55-57 for the pixels cpp:70-76 read, then the points
+            def launch(self):
                 c3.median_roi_device(raw.data_ptr(), W4K, H4K, W4K, W4K * H4K, a.frames, b3.disp.data_ptr(), W4K,
                                      W4K * H4K, 11, s3)
                 b3.launch(scale=0.125)
 
-        _, kms = timed_steps(_Body(), max(a.steps // 8, 5), 3, lambda: None)
+        _, kms = timed_steps(_Body(), max(a.steps // 2, 10), 5, lambda: None)
+        _, kms2 = timed_steps(_TwoLaunches(), max(a.steps // 2, 10), 5, lambda: None)
         variants["callback_u8_median11_parity_border40"] = {
             "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": round(kms, 4),
-            "what": "k_median_u8<11> over the inset ROI + k_reproject_pack<U8> per step"}
+            "what": "d2pc_process_mono_device: k_callback_bs<11> (bit-sliced median of a tile + its points from LDS) per step",
+            "as_two_launches_ms": round(kms2, 4),
+            "as_two_launches_what": "k_median_bs_u8<11> over the inset ROI + k_reproject_pack<U8>"}
         b3.disp.copy_(raw)
         _, kms = timed_steps(b3, max(a.steps // 4, 5), 3, lambda: None)
         ab = a.frames * b3.roi_n * 17

@@ -290,22 +290,23 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
  * output arguments).  dtype is D2PC_DTYPE_U8 or D2PC_DTYPE_MONO16;
  * median_ksize 0/1 skips the filter.
  *
- * The median is VALU-bound and the reprojection HBM-bound, which invites
- * overlapping them.  The tuning key "callback_chunks" (default 1 = off) cuts a
- * big batch into that many chunks and filters chunk c+1 on one internal stream
- * while chunk c is reprojected on another.  It is OFF by default because it
- * did not pay on MI355X / ROCm 7.2 (profiles/r02_callback_overlap.txt): the
- * two kernels running freely side by side finish only 8 % (shared CUs) to
- * 15 % (disjoint CU sets) sooner than back to back -- the reprojection's own
- * arithmetic competes with the filter for the same VALUs -- and every
- * cross-stream dependency of a real pipeline costs ~20 us, so 2 chunks of
- * 16 x 4K ranged from +8 % to -10 % between devices and finer chunks were
- * always slower than no overlap.  The one-kernel form the overlap really wants -- a
- * persistent kernel whose blocks switch between filter tiles and reprojection tiles,
- * handing frames over in-kernel -- exists as well (tuning key "callback_fused",
- * 11 x 11 / 8-bit / PARITY batches; bit-identical output) and is off for the same
- * reason: 1.4x SLOWER than the two launches (DESIGN.md section 9 says why).
- * Results never depend on either setting.
+ * With the default tuning, PARITY mode, an 11x11 (or 9x9) window and a launch of
+ * at least 448 tiles of 256 x 32 ROI pixels (one 4K frame has 975) the call is ONE
+ * kernel that works tile by tile: the bit-sliced median of the tile, then the
+ * tile's points straight from the filtered bytes in LDS -- for stereoRectify's Q
+ * through a per-block table of 1/W and Z over the 256 byte values.  The filtered
+ * frames never reach memory; 16 x 4K: 594 us against 818 us for the two launches
+ * (profiles/r02_median_bitsliced.txt).  Everything else -- COMPACT mode, small
+ * launches, other windows -- is the filter launch followed by the reprojection
+ * launch.  The results are the same bytes either way.
+ * Tuning "callback_fused": 2 (default) as described; 0 always two launches; 1 an
+ * earlier attempt kept for the record: one persistent kernel whose blocks switch
+ * between filter tiles and reprojection tiles and hand frames over in-kernel
+ * (1.4x slower than two launches: DESIGN.md section 9).  "callback_chunks"
+ * (default 1 = off) cuts a two-launch batch into chunks pipelined over two
+ * internal streams: the two kernels side by side finish only 8-15 % sooner than
+ * back to back and every cross-stream dependency costs ~20 us, so it ranged from
+ * +8 % to -10 % (profiles/r02_callback_overlap.txt).
  * The filtered frames live in context-owned scratch (grown on demand, so the
  * first call of a size is not capturable; under stream capture the call runs
  * in order on `stream`).
@@ -458,7 +459,7 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
  * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
  * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
- * "callback_fused" (0/1: the heterogeneous persistent kernel there; default 0),
+ * "callback_fused" (0, 1 or 2, see d2pc_process_mono_device; default 2),
  * "median_algo" (0 = choose per launch, 1 = one pixel per thread, 2 = 32 pixels per thread bit-sliced -- 9x9 and
  * 11x11 only, otherwise 1 is taken; the two give identical bytes). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);

@@ -23,7 +23,8 @@ def t(fn, iters=10, rounds=5):
     return float(np.median(ts))
 
 q = d2pc.make_q()
-torch.cuda.set_stream(torch.cuda.Stream())  # not the legacy default stream (it synchronises with every blocking stream)
+if not os.environ.get("D2PC_BENCH_DEFAULT_STREAM"):
+    torch.cuda.set_stream(torch.cuda.Stream())  # not the legacy default stream (it synchronises with every blocking stream)
 s = torch.cuda.current_stream().cuda_stream
 for (w, h, n) in ((752, 480, 64), (1920, 1080, 16), (3840, 2160, 16)):
     ctx = d2pc.Context(q=q)
