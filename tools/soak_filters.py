@@ -27,7 +27,9 @@ for c in range(cases):
     # ---- median ----
     k = int(rng.choice([3, 5, 7, 9, 11])); n = int(rng.integers(1, 4))
     h, w = int(rng.integers(1, 260)), int(rng.integers(1, 400))
+    if rng.random() < 0.2: w = int(rng.integers(400, 1100))   # several 256-wide tiles of the bit-sliced kernel
     sp, dp = w + int(rng.integers(0, 9)), w + int(rng.integers(0, 9))
+    ctx.set_tuning("median_algo", int(rng.integers(0, 3)))   # 0 the library's choice, 1 per pixel, 2 bit-sliced (k = 9, 11)
     imgs = [image(h, w) for _ in range(n)]
     src = torch.zeros((n, h, sp), dtype=torch.uint8, device="cuda"); src[:, :, :w] = torch.from_numpy(np.stack(imgs)).cuda()
     dst = torch.full((n, h, dp), 9, dtype=torch.uint8, device="cuda")
