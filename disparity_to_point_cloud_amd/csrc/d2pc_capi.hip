@@ -75,6 +75,7 @@ struct d2pc_ctx {
   d2pc_stage_times times{};
   bool have_times = false;
   int fuse_rows = 0;             // d2pc_fuse_device rows per wave: 0 = choose, else 2..1024
+  int host_direct_read = 1;      // synchronous host entry points: a PINNED input frame is read by the first kernel in place
   int median_algo = 0;           // MedianArgs::algo: 0 choose per launch, 1 per-pixel select, 2 bit-sliced (k = 9, 11)
   // device scratch
   StateBuf states[kMaxStateBufs];  // compaction state, one per stream with COMPACT work in flight
@@ -757,6 +758,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "callback_chunks") && value >= 0 && value <= 64) ctx->cb_chunks = value;
   else if (!strcmp(key, "callback_fused") && value >= 0 && value <= 2) ctx->cb_fused = value;
+  else if (!strcmp(key, "host_direct_read") && (value == 0 || value == 1)) ctx->host_direct_read = value;
   else if (!strcmp(key, "median_algo") && value >= 0 && value <= 2) ctx->median_algo = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
@@ -885,7 +887,16 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
     return fail(ctx, D2PC_ERR_CAPACITY, "capacity %zu < %u ROI points", capacity, g.roi_n);
   // the kernel sees the packed (and, for mono16, rescaled) copy
   if ((st = make_geom(ctx, kdtype, scale, width, height, kpitch, 0, 1, 0, pxt, &g)) != D2PC_OK) return st;
-  if ((st = grow(ctx, &ctx->d_in, &ctx->in_cap, pitch * size_t(height))) != D2PC_OK) return st;
+  // pinned input: the reprojection reads the frame straight from host memory (no staging copy; PCIe is full
+  // duplex, so with a pinned output the inbound reads overlap the outbound stores: one 4K fp32 frame 2.99 ->
+  // 2.53 ms, the native frame 128 -> 115 us).  Only when the reprojection is the first kernel and reads the frame
+  // once: the median's 32-byte row pieces crawl over the link (native frame 117 -> 161 us), and the two-pass
+  // compaction would fetch the frame twice.
+  const Geom g_caller = [&] { Geom t; (void)make_geom(ctx, dtype, scale, width, height, row_stride, 0, 1, 0, pxt, &t); return t; }();
+  const void *direct_in = nullptr;
+  if (ctx->host_direct_read && !median && !bridge16 && !compact && reinterpret_cast<uintptr_t>(disp) % es == 0)
+    direct_in = pinned_device_view(disp, row_stride * size_t(height - 1) + size_t(width) * es);
+  if (!direct_in && (st = grow(ctx, &ctx->d_in, &ctx->in_cap, pitch * size_t(height))) != D2PC_OK) return st;
   if (bridge16 && (st = grow(ctx, &ctx->d_cvt, &ctx->cvt_cap, kpitch * size_t(height))) != D2PC_OK) return st;
   if (median && (st = grow(ctx, &ctx->d_med, &ctx->med_cap, kpitch * size_t(height))) != D2PC_OK) return st;
   // pinned output that holds the whole ROI: the kernels store the final bytes straight into it
@@ -906,26 +917,32 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
       if (!e) D2PC_HIP(ctx, hipEventCreate(&e));
   auto mark = [&](int i) { return timing ? hipEventRecord(ctx->ev[i], s) : hipSuccess; };
   D2PC_HIP(ctx, mark(0));
-  D2PC_HIP(ctx, hipMemcpy2DAsync(ctx->d_in, pitch, disp, row_stride, size_t(width) * es, size_t(height),
-                                 hipMemcpyHostToDevice, s));
+  if (!direct_in)
+    D2PC_HIP(ctx, hipMemcpy2DAsync(ctx->d_in, pitch, disp, row_stride, size_t(width) * es, size_t(height),
+                                   hipMemcpyHostToDevice, s));
   D2PC_HIP(ctx, mark(1));
-  const void *kernel_in = ctx->d_in;
+  const void *kernel_in = direct_in ? direct_in : ctx->d_in;
+  size_t kernel_in_pitch = direct_in ? row_stride : pitch;
   MedianArgs m;
   m.algo = ctx->median_algo;
   m.width = uint32_t(width);
   m.height = uint32_t(height);
   if (bridge16) {
-    m.src_row_stride = uint32_t(pitch);
+    m.src_row_stride = uint32_t(kernel_in_pitch);
     m.dst_row_stride = uint32_t(kpitch);
-    D2PC_HIP(ctx, launch_mono16_to_mono8(ctx->d_in, ctx->d_cvt, m, s));
+    D2PC_HIP(ctx, launch_mono16_to_mono8(kernel_in, ctx->d_cvt, m, s));
     kernel_in = ctx->d_cvt;
+    kernel_in_pitch = kpitch;
   }
   if (median) {
-    m.src_row_stride = m.dst_row_stride = uint32_t(kpitch);
+    m.src_row_stride = uint32_t(kernel_in_pitch);
+    m.dst_row_stride = uint32_t(kpitch);
     median_roi_only(m, g, height);
     D2PC_HIP(ctx, launch_median(kernel_in, ctx->d_med, m, median_ksize, s));
     kernel_in = ctx->d_med;
+    kernel_in_pitch = kpitch;
   }
+  if (kernel_in == direct_in) g = g_caller;  // the reprojection itself reads the caller's rows
   D2PC_HIP(ctx, mark(2));
   void *kout = direct_out ? direct_out : ctx->d_out;
   uint32_t *kidx = !out_index ? nullptr : static_cast<uint32_t *>(direct_out ? direct_idx : ctx->d_idx);

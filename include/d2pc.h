@@ -324,7 +324,11 @@ int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int dtype, int 
  * (capacity_points >= ROI points), the kernels store the final PointCloud2
  * bytes straight into it over PCIe: no device-side copy of the cloud, no
  * D2H copy, no bounce through the runtime's staging buffers.  A pinned `disp`
- * / `image` makes the upload one DMA.  Pageable buffers keep working as before.
+ * / `image` is read by the reprojection kernel in place when that kernel is the
+ * first to touch it (PARITY, no median, no mono16 rescale: the inbound reads
+ * then overlap the outbound stores on the full-duplex link -- one 4K fp32 frame
+ * 2.99 -> 2.53 ms, one native frame 128 -> 115 us); otherwise it makes the
+ * upload one DMA.  Pageable buffers keep working as before.
  * host/pinned_allocator.hpp wraps these two in a caching std::allocator so that
  * sensor_msgs::PointCloud2_<Alloc>::data can be such a buffer.
  */
@@ -460,7 +464,8 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
  * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
  * "callback_fused" (0, 1 or 2, see d2pc_process_mono_device; default 2),
- * "median_algo" (0 = choose per launch, 1 = one pixel per thread, 2 = 32 pixels per thread bit-sliced -- 9x9 and
+ * "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process / d2pc_process_mono8
+ * without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose per launch, 1 = one pixel per thread, 2 = 32 pixels per thread bit-sliced -- 9x9 and
  * 11x11 only, otherwise 1 is taken; the two give identical bytes). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 

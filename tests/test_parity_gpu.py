@@ -405,3 +405,30 @@ def test_pinned_output_is_written_directly_and_matches_the_staged_path(q_default
             small.close()
     pts_buf.close()
     idx_buf.close()
+
+
+@pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
+def test_pinned_input_is_read_in_place(mode, q_default):
+    """A frame that lies in pinned host memory is read by the first kernel straight from there (no staging copy):
+    fp32 through d2pc_process (rows with a pitch), mono8 and mono16 through the median entry points.  Same bytes
+    as from pageable memory and as with the tuning key host_direct_read = 0."""
+    rng = np.random.default_rng(31 + mode)
+    h, w, pitch = 300, 412, 420
+    f32 = d2pc.PinnedBuffer((h, pitch), np.float32)
+    f32.array[:] = synth_disparity(2, 3, pitch, h, "holes")
+    u8 = d2pc.PinnedBuffer((h, pitch), np.uint8)
+    u8.array[:] = rng.integers(0, 256, size=(h, pitch)).astype(np.uint8)
+    u16 = d2pc.PinnedBuffer((h, pitch), np.uint16)
+    u16.array[:] = rng.integers(0, 65536, size=(h, pitch)).astype(np.uint16)
+    with ctx_for(q_default, mode=mode) as ctx:
+        for direct in (1, 0):
+            ctx.set_tuning("host_direct_read", direct)
+            for pinned, run in ((f32.array[:, :w], lambda a: ctx.process(a, want_index=True)),
+                                (u8.array[:, :w], lambda a: ctx.process_mono8(a, 11, 0.125, want_index=True)),
+                                (u8.array[:, :w], lambda a: ctx.process_mono8(a, 0, 0.125, want_index=True)),
+                                (u16.array[:, :w], lambda a: ctx.process_mono16(a, 11, 0.125, want_index=True))):
+                got_p, got_i = run(pinned)
+                want_p, want_i = run(np.ascontiguousarray(pinned))   # a pageable copy
+                assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32)) and np.array_equal(got_i, want_i)
+    for b in (f32, u8, u16):
+        b.close()
