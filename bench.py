@@ -219,6 +219,26 @@ def host_path_rates(q, border):
         dt = (time.perf_counter() - t0) / k
         res["sync_d2pc_process"] = {"ms_per_frame": round(dt * 1e3, 3), "Mpixels_per_s": round(W4K * H4K / dt / 1e6, 1),
                                     "pcie_GBs": round((fr.nbytes + n.value * 16) / dt / 1e9, 1)}
+        # the same call with frame and cloud in pinned memory (d2pc_host_alloc): the kernel reads and writes them in place
+        pin_in, pin_out = d2pc.PinnedBuffer((H4K, W4K), np.float32), d2pc.PinnedBuffer((cap, 4), np.float32)
+        pin_in.array[:] = fr
+
+        def once_pinned():
+            st = L.d2pc_process(ctx.handle, pin_in.array.ctypes.data, 0, 1.0, W4K, H4K, W4K * 4, pin_out.array.ctypes.data,
+                                None, cap, ctypes.byref(n))
+            assert st == 0, st
+        for _ in range(2):
+            once_pinned()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.5:
+            once_pinned()
+            k += 1
+        dt = (time.perf_counter() - t0) / k
+        res["sync_d2pc_process_pinned_io"] = {"ms_per_frame": round(dt * 1e3, 3),
+                                              "Mpixels_per_s": round(W4K * H4K / dt / 1e6, 1),
+                                              "pcie_GBs": round((fr.nbytes + n.value * 16) / dt / 1e9, 1)}
+        pin_in.close()
+        pin_out.close()
     with d2pc.Context(q=q, border=border) as ctx:
         ctx.pipeline_configure(depth=3, direct_host_write=True)
         desc = FrameDesc(0, 1.0, W4K, H4K, W4K * 4, 0, 0, 0)
