@@ -375,3 +375,26 @@ def test_tile_fused_callback_kernel_matches_the_two_launches_and_the_oracle(gene
         want = oracle.reproject(oracle.median_u8(np.ascontiguousarray(imgs[f, :, :w]), k), q, border=border, scale=scale)
         assert res[2][2].view(np.uint32)[f] == len(want)
         assert_points_close(pts[f][:len(want)], want, max_ulp=1, rel=1e-5, what=f"frame {f}")
+
+
+@pytest.mark.parametrize("scale", [float("inf"), float("nan"), -0.125, 3.0e38, 0.0, 1e-45])
+def test_tile_fused_callback_kernel_with_degenerate_scales(scale):
+    """The table of 1/W over the byte values must reproduce reproject()'s inf / NaN / signed-zero behaviour: byte 0
+    times inf is NaN, W = 0 gives infinities, FLT_MAX hits the bigZ rule ...  Bitwise against the two launches."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    n, h, w = 2, 90, 300
+    imgs = np.random.default_rng(3).integers(0, 256, size=(n, h, w)).astype(np.uint8)
+    imgs[0, :, :150] = 0
+    src = torch.from_numpy(imgs).cuda()
+    res = {}
+    with d2pc.Context(q=d2pc.make_q(), border=7) as ctx:
+        ctx.set_tuning("median_algo", 2)
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8)
+        for fused in (2, 0):
+            ctx.set_tuning("callback_fused", fused)
+            b.points.fill_(0)
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, scale, b.points.data_ptr(), None,
+                                    b.stride, b.counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            res[fused] = b.points.cpu().numpy().view(np.uint32).copy()
+    assert np.array_equal(res[2], res[0])
