@@ -22,6 +22,7 @@ WORKLOADS = {  # name: (mode, frames, W, H, border, hole fraction, blocky, indic
     "compact_1080p_x32":  ("compact", 32, 1920, 1080, 40, 0.3, 0, True, "f32"),
     "compact_1080p_x1":   ("compact", 1, 1920, 1080, 40, 0.3, 0, True, "f32"),
     "median11_roi":       ("median", 16, 3840, 2160, 40, 0.0, 0, False, "u8"),
+    "callback_u8":        ("callback", 16, 3840, 2160, 40, 0.0, 0, False, "u8"),
 }
 
 
@@ -53,7 +54,7 @@ def main():
     ap.add_argument("--scale", type=float, default=None)
     ap.add_argument("--tune", action="append", default=[], help="key=value for d2pc_set_tuning (repeatable)")
     a = ap.parse_args()
-    if WORKLOADS[a.workload][0] == "median":   # the 11 x 11 median over the inset ROI, 16 x 4K (cpp:55-57); --tune median_algo=1|2 picks the kernel
+    if WORKLOADS[a.workload][0] in ("median", "callback"):   # the 11 x 11 median over the inset ROI, 16 x 4K (cpp:55-57); --tune median_algo=1|2 picks the kernel
         _, F, W, H, border, *_ = WORKLOADS[a.workload]
         ctx = d2pc.Context(q=d2pc.make_q(), border=border)
         for kv in a.tune:
@@ -61,7 +62,13 @@ def main():
         raw = torch.randint(0, 256, (F, H, W), dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(raw)
         s = torch.cuda.current_stream().cuda_stream
-        run = lambda: ctx.median_roi_device(raw.data_ptr(), W, H, W, W * H, F, dst.data_ptr(), W, W * H, 11, s)
+        if WORKLOADS[a.workload][0] == "callback":   # d2pc_process_mono_device: k_callback_bs<11> at this size
+            from disparity_to_point_cloud_amd.torch_api import DeviceBatch as _DB
+            bb = _DB(ctx, F, H, W, dtype=torch.uint8)
+            run = lambda: ctx.process_mono_device(raw.data_ptr(), d2pc.DTYPE_U8, W, H, W, W * H, F, 11, 0.125,
+                                                  bb.points.data_ptr(), None, bb.stride, bb.counts.data_ptr(), s)
+        else:
+            run = lambda: ctx.median_roi_device(raw.data_ptr(), W, H, W, W * H, F, dst.data_ptr(), W, W * H, 11, s)
         run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -71,7 +78,7 @@ def main():
         ms = e0.elapsed_time(e1) / a.launches
         px = F * (W - 2 * border) * (H - 2 * border)
         print(json.dumps({"workload": a.workload, "launches": a.launches, "ms_per_launch": round(ms, 4), "points": px,
-                          "roi_pixels": px, "algorithmic_bytes": 2 * px, "algorithmic_GBs": round(2 * px / ms / 1e6, 1)}))
+                          "roi_pixels": px, "algorithmic_bytes": (17 if WORKLOADS[a.workload][0] == "callback" else 2) * px, "algorithmic_GBs": round((17 if WORKLOADS[a.workload][0] == "callback" else 2) * px / ms / 1e6, 1)}))
         return
     ctx, b = make_batch(a.workload, a.algo, tuning=[(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.tune])
     scale = a.scale if a.scale is not None else (0.125 if b.disp.dtype == torch.uint8 else 1.0)
