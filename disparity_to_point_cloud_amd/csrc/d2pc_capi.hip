@@ -1145,7 +1145,19 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
     if (capturing) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "scratch not allocated yet: run this batch size once before capturing");
     if ((st = grow(ctx, &ctx->d_cb_cvt, &ctx->cb_cvt_cap, kframe * size_t(n_frames))) != D2PC_OK) return st;
   }
-  if (median && kframe * size_t(n_frames) > ctx->cb_med_cap) {
+  // (the same decisions as below: chunked overlap?  filter + points in one kernel, which needs no filtered frames?)
+  const int want_chunks = ctx->cb_chunks > n_frames ? n_frames : ctx->cb_chunks;
+  const bool will_overlap = want_chunks > 1 && !capturing && (median || bridge16) &&
+                            uint64_t(width) * uint64_t(height) * uint64_t(n_frames) / uint64_t(want_chunks) >= (uint64_t(16) << 20);
+  bool one_kernel = false;
+  if (median && ctx->cb_fused == 2 && !compact && !will_overlap) {
+    MedianArgs probe;
+    probe.algo = ctx->median_algo;
+    probe.n_frames = uint32_t(n_frames);
+    median_roi_only(probe, gin, height);
+    one_kernel = median_uses_bs(probe, median_ksize);
+  }
+  if (median && !one_kernel && kframe * size_t(n_frames) > ctx->cb_med_cap) {
     if (capturing) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "scratch not allocated yet: run this batch size once before capturing");
     if ((st = grow(ctx, &ctx->d_cb_med, &ctx->cb_med_cap, kframe * size_t(n_frames))) != D2PC_OK) return st;
   }

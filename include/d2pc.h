@@ -307,9 +307,9 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
  * internal streams: the two kernels side by side finish only 8-15 % sooner than
  * back to back and every cross-stream dependency costs ~20 us, so it ranged from
  * +8 % to -10 % (profiles/r02_callback_overlap.txt).
- * The filtered frames live in context-owned scratch (grown on demand, so the
- * first call of a size is not capturable; under stream capture the call runs
- * in order on `stream`).
+ * In the two-launch form the filtered frames live in context-owned scratch
+ * (grown on demand, so the first call of a size is not capturable; under stream
+ * capture the call runs in order on `stream`); the one-kernel form needs none.
  */
 int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int dtype, int width, int height,
                              size_t row_stride_bytes, size_t frame_stride_bytes, int n_frames,
