@@ -469,7 +469,7 @@ class Context:
     def process_mono_device(self, d_image_ptr, dtype, width, height, row_stride, frame_stride, n_frames, median_ksize,
                             scale, d_out_ptr, d_index_ptr, out_frame_stride_points, d_counts_ptr, stream_ptr=None):
         """d2pc_process_mono_device: (rescale ->) median(ROI) -> reproject for a device-resident batch.  PARITY
-        mode, k = 9 or 11 and a launch of >= 448 tiles: one kernel, tile by tile (bit-sliced median + the tile's
+        mode and a launch of >= 448 tiles (192 / 320 for 3x3 / 5x5): one kernel, tile by tile (bit-sliced median + the tile's
         points); otherwise the filter launch followed by the reprojection launch (tuning "callback_fused")."""
         self._check(self._L.d2pc_process_mono_device(self._h, d_image_ptr, dtype, width, height, row_stride,
                                                      frame_stride, n_frames, median_ksize, scale, d_out_ptr,

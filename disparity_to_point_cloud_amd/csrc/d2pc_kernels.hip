@@ -1540,7 +1540,7 @@ hipError_t launch_callback_fused(const LaunchArgs &a, MedianArgs m, const void *
 }
 
 hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src, int ksize) {
-  if ((ksize != 9 && ksize != 11) || m.out_w == 0 || m.out_h == 0) return hipErrorInvalidValue;
+  if (!median_ksize_supported(ksize) || m.out_w == 0 || m.out_h == 0) return hipErrorInvalidValue;
   if (m.out_x0 != a.geom.border || m.out_y0 != a.geom.border || m.out_w != a.geom.roi_w ||
       uint64_t(m.out_w) * m.out_h != a.geom.roi_n)
     return hipErrorInvalidValue;  // the filter's output rectangle must be the reprojection's ROI
@@ -1554,12 +1554,18 @@ hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src
 #define D2PC_CB_BS(KS, QK)                                                                                              \
   hipLaunchKernelGGL((k_callback_bs<KS, QK>), dim3(uint32_t(blocks)), dim3(S::THREADS), 0, a.stream, s8, o, a.out_index, \
                      a.counts, m, a.geom, make_qarg<QK>(a))
-  if (ksize == 11) {
-    if (a.q_kind == QK_STEREO) D2PC_CB_BS(11, QK_STEREO);
-    else D2PC_CB_BS(11, QK_GENERAL);
-  } else {
-    if (a.q_kind == QK_STEREO) D2PC_CB_BS(9, QK_STEREO);
-    else D2PC_CB_BS(9, QK_GENERAL);
+  switch (ksize * 2 + (a.q_kind == QK_STEREO ? 1 : 0)) {
+    case 6: D2PC_CB_BS(3, QK_GENERAL); break;
+    case 7: D2PC_CB_BS(3, QK_STEREO); break;
+    case 10: D2PC_CB_BS(5, QK_GENERAL); break;
+    case 11: D2PC_CB_BS(5, QK_STEREO); break;
+    case 14: D2PC_CB_BS(7, QK_GENERAL); break;
+    case 15: D2PC_CB_BS(7, QK_STEREO); break;
+    case 18: D2PC_CB_BS(9, QK_GENERAL); break;
+    case 19: D2PC_CB_BS(9, QK_STEREO); break;
+    case 22: D2PC_CB_BS(11, QK_GENERAL); break;
+    case 23: D2PC_CB_BS(11, QK_STEREO); break;
+    default: return hipErrorInvalidValue;
   }
 #undef D2PC_CB_BS
   return hipGetLastError();

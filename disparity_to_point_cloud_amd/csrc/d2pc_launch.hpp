@@ -40,8 +40,7 @@ struct MedianArgs {
   // inset ROI (cpp:70,72 read nothing else of the filtered image).
   uint32_t out_x0 = 0, out_y0 = 0, out_w = 0, out_h = 0;
   uint32_t tiles_x = 0, tiles_y = 0;                // filled by launch_median
-  // 0: choose per launch; 1: one pixel per thread (d2pc_median.hip); 2: bit-sliced across pixels
-  // (d2pc_median_bs.hip; k = 9 and 11 only, otherwise 1 is taken)
+  // 0: choose per launch; 1: one pixel per thread (d2pc_median.hip); 2: bit-sliced across pixels (d2pc_median_bs.hip)
   int algo = 0;
 };
 bool median_ksize_supported(int k);
@@ -95,7 +94,7 @@ hipError_t launch_parity(const LaunchArgs &a);
 size_t fused_sync_bytes(uint32_t n_frames);
 hipError_t launch_callback_fused(const LaunchArgs &a, MedianArgs m, const void *src, void *med, int ksize, void *sync,
                                  uint32_t blocks, uint32_t spin_ticks);
-// tile-fused callback body (bit-sliced k x k median, k = 9 or 11, + PARITY reprojection of the tile from LDS;
+// tile-fused callback body (bit-sliced k x k median + PARITY reprojection of the tile from LDS;
 // k_callback_bs): `m` carries the filter's geometry with the output rectangle = the ROI of a.geom; a.out_points,
 // a.out_index (nullable), a.counts (nullable), a.q*, a.stream as in launch_parity
 hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src, int ksize);

@@ -107,15 +107,15 @@ hipError_t launch_k(const uint8_t *s, uint8_t *d, MedianArgs a, hipStream_t stre
 }
 }  // namespace
 
-// The bit-sliced kernel works on 256 x 32 tiles, three 4-wave blocks per CU, ~20 us per block: it pays once
-// the launch has about two thirds of a chipful of tiles (profiles/r02_median_bitsliced.txt: 312 tiles 0.86x,
-// 512 tiles 1.11x, 15,600 tiles 1.46x the per-pixel kernel); below that (one native 752x480 frame is 39
-// tiles, 7 us) the per-pixel kernel's 18 x 64 tiles spread better.
-constexpr uint64_t kBsMinTiles = 448;
+// The bit-sliced kernel works on 256 x 32 tiles, three or four 4-wave blocks per CU, ~8 (3 x 3) to ~20 us (11 x 11)
+// per block: it pays once the launch has a good fraction of a chipful of tiles (profiles/r02_median_bitsliced.txt,
+// 11 x 11: 312 tiles 0.86x, 512 tiles 1.11x, 15,600 tiles 1.46x the per-pixel kernel; 3 x 3: 156 tiles 1.01x, 15,600
+// tiles 2.84x); below that (one native 752x480 frame is 39 tiles, 4-7 us) the per-pixel kernel's small tiles spread better.
+constexpr uint64_t bs_min_tiles(int ksize) { return ksize <= 3 ? 192 : ksize <= 5 ? 320 : 448; }
 
 bool median_uses_bs(const MedianArgs &a, int ksize) {
-  return (ksize == 9 || ksize == 11) && a.out_w != 0 && a.out_h != 0 &&
-         (a.algo == 2 || (a.algo == 0 && median_bs_tiles(a) >= kBsMinTiles));
+  return median_ksize_supported(ksize) && a.out_w != 0 && a.out_h != 0 &&
+         (a.algo == 2 || (a.algo == 0 && median_bs_tiles(a) >= bs_min_tiles(ksize)));
 }
 
 hipError_t launch_median(const void *src, void *dst, const MedianArgs &args, int ksize, hipStream_t stream) {

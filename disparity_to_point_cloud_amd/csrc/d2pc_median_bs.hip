@@ -59,6 +59,9 @@ hipError_t launch_median_bs(const void *src, void *dst, const MedianArgs &a, int
   const uint8_t *s = static_cast<const uint8_t *>(src);
   uint8_t *d = static_cast<uint8_t *>(dst);
   switch (ksize) {
+    case 3: return launch_bs<3>(s, d, a, stream);
+    case 5: return launch_bs<5>(s, d, a, stream);
+    case 7: return launch_bs<7>(s, d, a, stream);
     case 9: return launch_bs<9>(s, d, a, stream);
     case 11: return launch_bs<11>(s, d, a, stream);
     default: return hipErrorInvalidValue;

@@ -290,14 +290,14 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
  * output arguments).  dtype is D2PC_DTYPE_U8 or D2PC_DTYPE_MONO16;
  * median_ksize 0/1 skips the filter.
  *
- * With the default tuning, PARITY mode, an 11x11 (or 9x9) window and a launch of
- * at least 448 tiles of 256 x 32 ROI pixels (one 4K frame has 975) the call is ONE
+ * With the default tuning, PARITY mode and a launch of at least 448 tiles of
+ * 256 x 32 ROI pixels (one 4K frame has 975; 192 / 320 tiles for 3x3 / 5x5 windows) the call is ONE
  * kernel that works tile by tile: the bit-sliced median of the tile, then the
  * tile's points straight from the filtered bytes in LDS -- for stereoRectify's Q
  * through a per-block table of 1/W and Z over the 256 byte values.  The filtered
  * frames never reach memory; 16 x 4K: 594 us against 818 us for the two launches
  * (profiles/r02_median_bitsliced.txt).  Everything else -- COMPACT mode, small
- * launches, other windows -- is the filter launch followed by the reprojection
+ * launches -- is the filter launch followed by the reprojection
  * launch.  The results are the same bytes either way.
  * Tuning "callback_fused": 2 (default) as described; 0 always two launches; 1 an
  * earlier attempt kept for the record: one persistent kernel whose blocks switch
@@ -465,8 +465,8 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
  * "callback_fused" (0, 1 or 2, see d2pc_process_mono_device; default 2),
  * "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process / d2pc_process_mono8
- * without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose per launch, 1 = one pixel per thread, 2 = 32 pixels per thread bit-sliced -- 9x9 and
- * 11x11 only, otherwise 1 is taken; the two give identical bytes). */
+ * without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose per launch,
+ * 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

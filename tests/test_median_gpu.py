@@ -34,7 +34,7 @@ def test_median_matches_oracle(k, w, h):
         assert np.array_equal(g, oracle.median_u8(img, k))
 
 
-@pytest.mark.parametrize("k", [9, 11])
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 11])
 @pytest.mark.parametrize("w,h", [(752, 480), (97, 131), (256, 32), (257, 33), (300, 70), (5, 3), (1, 1), (1, 40), (40, 1),
                                  (1037, 45)])
 def test_bit_sliced_median_matches_oracle(k, w, h):
@@ -338,7 +338,8 @@ def test_fused_callback_kernel_matches_the_two_launches_and_the_oracle(shape):
 @pytest.mark.parametrize("general_q", [0, 1])
 @pytest.mark.parametrize("k,shape,border,scale", [(11, (3, 480, 752), 40, 0.125), (11, (2, 131, 203), 7, 0.37),
                                                   (9, (2, 300, 408), 40, 0.125), (11, (1, 97, 600), 0, 1.0),
-                                                  (11, (2, 1080, 1920), 40, 0.125)])
+                                                  (11, (2, 1080, 1920), 40, 0.125), (3, (2, 200, 520), 3, 0.125),
+                                                  (5, (1, 131, 203), 0, 0.5), (7, (2, 90, 300), 11, 0.125)])
 def test_tile_fused_callback_kernel_matches_the_two_launches_and_the_oracle(general_q, k, shape, border, scale):
     """k_callback_bs: the bit-sliced median of a 256 x 32 tile and, from the filtered bytes still in LDS, the tile's
     points (for stereoRectify's Q through a per-block table of 1/W and Z over the 256 byte values).  Forced onto

@@ -22,7 +22,8 @@ def t(fn, iters=20, rounds=5):
 torch.cuda.set_stream(torch.cuda.Stream())
 s = torch.cuda.current_stream().cuda_stream
 ctx = d2pc.Context(q=d2pc.make_q())
-print("size x frames: 256x32 tiles (ROI, border 40) | per-pixel us | bit-sliced us | ratio")
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 11
+print(f"k = {K}; size x frames: 256x32 tiles (ROI, border 40) | per-pixel us | bit-sliced us | ratio")
 for (w, h) in ((752, 480), (1920, 1080), (3840, 2160)):
     for n in (1, 2, 4, 8, 16, 32):
         if w * h * n > 3840 * 2160 * 16: continue
@@ -32,5 +33,5 @@ for (w, h) in ((752, 480), (1920, 1080), (3840, 2160)):
         us = []
         for algo in (1, 2):
             ctx.set_tuning("median_algo", algo)
-            us.append(t(lambda: ctx.median_roi_device(raw.data_ptr(), w, h, w, w * h, n, out.data_ptr(), w, w * h, 11, s)))
+            us.append(t(lambda: ctx.median_roi_device(raw.data_ptr(), w, h, w, w * h, n, out.data_ptr(), w, w * h, K, s)))
         print(f"{w}x{h} x{n:2d}: {tiles:6d} tiles  {us[0]:8.1f}  {us[1]:8.1f}  {us[0]/us[1]:.2f}", flush=True)

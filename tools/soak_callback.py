@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of d2pc_process_mono_device against the oracle: the tile-fused kernel (k_callback_bs: bit-sliced
 median of a tile + the tile's points) forced onto random sizes, borders, pitches, scales, both forms of Q, with and
-without indices, U8 and MONO16 input, window 9 and 11; every case also runs as two launches and must give the same
+without indices, U8 and MONO16 input, all window sizes; every case also runs as two launches and must give the same
 bytes.  GPU box:  python tools/soak_callback.py [cases] [seed]"""
 import os, sys, time
 import numpy as np, torch
@@ -17,7 +17,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 t0 = time.time()
 for c in range(cases):
-    k = int(rng.choice([9, 11])); n = int(rng.integers(1, 4))
+    k = int(rng.choice([3, 5, 7, 9, 11])); n = int(rng.integers(1, 4))
     h, w = int(rng.integers(1, 300)), int(rng.integers(1, 900))
     border = int(rng.choice([0, 1, 7, 40]))
     scale = float(rng.choice([0.125, 1.0, 0.37, 1e-3]))
