@@ -399,3 +399,29 @@ def test_tile_fused_callback_kernel_with_degenerate_scales(scale):
             torch.cuda.synchronize()
             res[fused] = b.points.cpu().numpy().view(np.uint32).copy()
     assert np.array_equal(res[2], res[0])
+
+
+def test_tile_fused_callback_kernel_is_capturable_without_a_warm_up_call():
+    """The one-kernel form needs no scratch for filtered frames, so the very first call of a size may already be
+    inside a stream capture; the graph replays onto wiped outputs."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    q = d2pc.make_q()
+    n, h, w = 3, 200, 520
+    imgs = np.random.default_rng(8).integers(0, 256, size=(n, h, w)).astype(np.uint8)
+    src = torch.from_numpy(imgs).cuda()
+    with d2pc.Context(q=q) as ctx:
+        ctx.set_tuning("median_algo", 2)
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125, b.points.data_ptr(), None,
+                                    b.stride, b.counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        for _ in range(2):
+            b.points.fill_(0)
+            b.counts.fill_(0)
+            g.replay()
+            res = b.results()
+            for f in range(n):
+                want = oracle.reproject(oracle.median_u8(imgs[f], 11), q, border=40, scale=0.125)
+                assert_points_close(res[f][0], want, max_ulp=1, what=f"replayed frame {f}")
