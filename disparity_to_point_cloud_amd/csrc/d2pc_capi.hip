@@ -88,10 +88,9 @@ struct d2pc_ctx {
   uint32_t *d_counts = nullptr;
   uint32_t *h_counts = nullptr;  // pinned
   // d2pc_process_mono_device: two internal streams + scratch for the filtered frames
-  int cb_fused = 2;              // d2pc_process_mono_device, median + PARITY reprojection in one kernel: 0 never; 2 tile by
-                                 // tile (k_callback_bs: bit-sliced median, the tile's points from LDS) when the launch is
-                                 // large enough for the bit-sliced filter; 1 the persistent two-role kernel
-                                 // (k_callback_fused): correct, but slower than two launches -- DESIGN section 9
+  int cb_fused = 1;              // d2pc_process_mono_device, PARITY: median + points in one kernel, tile by tile (k_callback_bs:
+                                 // bit-sliced median, the tile's points from LDS) when the launch is large enough for the
+                                 // bit-sliced filter; 0 = always the filter launch followed by the reprojection launch
   int cb_chunks = 1;             // pipeline chunks per call (<= 1: everything in order on the caller's stream;
                                  // overlapping did not pay reliably: profiles/r02_callback_overlap.txt)
   hipStream_t cb_stream_m = nullptr, cb_stream_r = nullptr;
@@ -757,7 +756,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "callback_chunks") && value >= 0 && value <= 64) ctx->cb_chunks = value;
-  else if (!strcmp(key, "callback_fused") && value >= 0 && value <= 2) ctx->cb_fused = value;
+  else if (!strcmp(key, "callback_fused") && (value == 0 || value == 1)) ctx->cb_fused = value;
   else if (!strcmp(key, "host_direct_read") && (value == 0 || value == 1)) ctx->host_direct_read = value;
   else if (!strcmp(key, "median_algo") && value >= 0 && value <= 2) ctx->median_algo = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
@@ -1150,7 +1149,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
   const bool will_overlap = want_chunks > 1 && !capturing && (median || bridge16) &&
                             uint64_t(width) * uint64_t(height) * uint64_t(n_frames) / uint64_t(want_chunks) >= (uint64_t(16) << 20);
   bool one_kernel = false;
-  if (median && ctx->cb_fused == 2 && !compact && !will_overlap) {
+  if (median && ctx->cb_fused == 1 && !compact && !will_overlap) {
     MedianArgs probe;
     probe.algo = ctx->median_algo;
     probe.n_frames = uint32_t(n_frames);
@@ -1160,43 +1159,6 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
   if (median && !one_kernel && kframe * size_t(n_frames) > ctx->cb_med_cap) {
     if (capturing) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "scratch not allocated yet: run this batch size once before capturing");
     if ((st = grow(ctx, &ctx->d_cb_med, &ctx->cb_med_cap, kframe * size_t(n_frames))) != D2PC_OK) return st;
-  }
-  // The reference's own constants (11 x 11, 8-bit, everything published) on a batch: one persistent kernel in which
-  // the filter and the reprojection run side by side on every CU (k_callback_fused)
-  if (ctx->cb_fused == 1 && median && median_ksize == 11 && !bridge16 && !compact && !d_idx && n_frames >= 2) {
-    Geom g;
-    if ((st = make_geom(ctx, D2PC_DTYPE_U8, scale, width, height, kpitch, kframe, n_frames, out_frame_stride, 8, &g)) != D2PC_OK)
-      return st;
-    StateBuf *sb = nullptr;
-    if ((st = acquire_state(ctx, user, (fused_sync_bytes(uint32_t(n_frames)) + 15) & ~size_t(15), nullptr, &sb)) != D2PC_OK) return st;
-    sb->algo = 0;
-    LaunchArgs a;
-    a.out_points = d_out;
-    a.counts = d_counts;
-    a.dtype = D2PC_DTYPE_U8;
-    a.pxt = 8;
-    a.stream = user;
-    a.geom = g;
-    memcpy(a.q.q, ctx->q, sizeof a.q.q);
-    a.qs = ctx->qs;
-    a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
-    MedianArgs m;
-    m.algo = ctx->median_algo;
-    m.width = uint32_t(width);
-    m.height = uint32_t(height);
-    m.n_frames = uint32_t(n_frames);
-    m.src_row_stride = uint32_t(row_stride);
-    m.dst_row_stride = uint32_t(kpitch);
-    m.src_frame_stride = frame_stride;
-    m.dst_frame_stride = kframe;
-    median_roi_only(m, gin, height);
-    const uint32_t blocks = uint32_t(ctx->cu_count) * 9u;  // 68 VGPRs (7 waves per SIMD), 7 KB LDS: 9 blocks of 3 waves per CU
-    D2PC_HIP(ctx, launch_callback_fused(a, m, d_image, ctx->d_cb_med, median_ksize, sb->p, blocks, g.spin_ticks));
-    if (!sb->captured) {
-      D2PC_HIP(ctx, hipEventRecord(sb->done, user));
-      sb->pending = true;
-    }
-    return D2PC_OK;
   }
   // Few, large chunks: a cross-stream dependency costs ~20 us on this runtime (measured: 16 one-frame chunks of
   // 4K frames are 19 % SLOWER than running in order, 2 chunks 8 % faster), so the batch is only cut when every
@@ -1245,7 +1207,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
       m.src_frame_stride = kin_frame;
       m.dst_frame_stride = kframe;
       median_roi_only(m, gin, height);
-      if (ctx->cb_fused == 2 && !compact && !overlap && median_uses_bs(m, median_ksize)) {
+      if (ctx->cb_fused == 1 && !compact && !overlap && median_uses_bs(m, median_ksize)) {
         // filter and points tile by tile in one kernel; the filtered frames never reach memory
         Geom g;
         if ((st = make_geom(ctx, D2PC_DTYPE_U8, scale, width, height, kin_pitch, kin_frame, nf, out_frame_stride, pxt, &g)) != D2PC_OK)

@@ -22,7 +22,6 @@
 #include "d2pc_device.hpp"
 #include "d2pc_launch.hpp"
 #include "d2pc_median_bs_tile.hpp"
-#include "d2pc_median_tile.hpp"
 
 namespace d2pc {
 
@@ -348,189 +347,13 @@ __global__ __launch_bounds__(kBlock) void k_reproject_pack(const uint8_t *__rest
 }
 
 // --------------------------------------------------------------------------
-// K1f: the callback body of a device-resident batch in ONE persistent kernel -- k x k median over the inset
-// ROI (cpp:55-57) and reprojection of the filtered 8-bit frames (cpp:60-85, PARITY) -- so that the VALU-bound
-// filter and the HBM-bound reprojection run side by side on every CU without launch or stream dependencies.
-//  * Blocks of 256 threads take chunks of work from two ticket counters: median tiles (frame-major) and
-//    reprojection tiles.  A reprojection tile may start once all median tiles of its frame are done
-//    (done[f], counted per chunk).
-//  * Every fourth block is reprojection-"home", the rest median-home: a block serves its home queue first and
-//    the other one whenever its own is empty or (reprojection) not ready yet, so nobody ever waits while
-//    there is work, and the filter never waits at all (no deadlock whatever the residency).
-//  * Cross-block hand-off without L2 flushes: the filter stores its bytes with agent-scope (sc1) stores and
-//    drains them before the chunk is counted; the reprojection reads them with sc1 loads (the per-XCD L2s are
-//    not coherent with each other).
-// --------------------------------------------------------------------------
-struct FusedSync {           // one 64-byte line per hot word
-  uint32_t m_ticket, pad0[15];
-  uint32_t r_ticket, pad1[15];
-  uint32_t roles, pad2[15];
-  uint32_t done[1];          // done[f]: median tiles of frame f finished (n_frames words follow)
-};
-// A returning atomic on ONE word serialises chip-wide at ~70 ns: chunks are large.  (Static assignment of the filter
-// chunks was tried and is worse: blocks busy reprojecting neglect their own share of a frame and hold its readiness back.)
-#ifndef D2PC_FUSED_MCHUNK
-#define D2PC_FUSED_MCHUNK 64
-#endif
-constexpr uint32_t kFusedMedianChunk = D2PC_FUSED_MCHUNK, kFusedReprojChunk = 16;
-
-__device__ __forceinline__ float load_u8_coherent(const uint8_t *frame, uint32_t byte_off, float scale) {
-  using gu8 = __attribute__((address_space(1))) const uint8_t;
-  return __fmul_rn(float(__hip_atomic_load((gu8 *)(frame + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), scale);
-}
-
-template <int KS, int QK, int PXT>
-__global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_callback_fused(
-    const uint8_t *__restrict__ src, uint8_t *med, float4 *__restrict__ out, uint32_t *__restrict__ counts, FusedSync *sync,
-    const MedianArgs ma, const Geom g, const QArg<QK> Q, const uint32_t r_per_frame, const uint32_t spin_ticks) {
-  // The block has the MEDIAN kernel's shape (192 threads at 11 x 11: every wave works in both roles -- 256-thread blocks
-  // with an idle fourth wave in the filter role cost the filter a third of its resident waves and ran it 53 % slower).
-  // A reprojection tile is therefore WAVES x 8 slots x 64 pixels, batches of WAVES x 256.
-  using S = MedianShape<KS>;
-  constexpr uint32_t WAVES = S::THREADS / 64, RBATCH = WAVES * 256u, RTILE = uint32_t(S::THREADS) * PXT;
-  __shared__ __attribute__((aligned(16))) uint32_t s_pair[S::LDS_WORDS];
-  __shared__ uint32_t s_cmd[4];  // {kind, first, count, -}
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t m_per_frame = ma.tiles_x * ma.tiles_y, m_total = m_per_frame * ma.n_frames;
-  const uint32_t r_total = r_per_frame * g.n_frames;
-  if (tid == 0) s_cmd[3] = atomicAdd(&sync->roles, 1u);
-  __syncthreads();
-  const bool r_home = (s_cmd[3] & 3u) == 3u;
-#ifndef D2PC_FUSED_NO_STAGGER
-  // All blocks start together and every filter tile costs the same, so without this they run in lockstep: every
-  // block of a CU loads rows at the same time (VALU idle) and selects at the same time.  A launched grid staggers
-  // itself as blocks retire; a persistent one has to be told: arrival k on its CU-ish neighbourhood waits k/9 of a tile.
-  for (uint32_t k = (s_cmd[3] >> 2) % 9u; k > 0; --k) __builtin_amdgcn_s_sleep(48);
-#endif
-  uint32_t pend_first = 0, pend_count = 0;  // a claimed reprojection chunk waiting for its frames (thread 0 only)
-  bool m_left = true, r_left = true;        // (thread 0 only)
-  for (;;) {
-    // ---- thread 0 decides the block's next step -------------------------------------------------------
-    if (tid == 0) {
-      uint32_t kind = 0, first = 0, count = 0;  // 0 = finished, 1 = median chunk, 2 = reprojection chunk
-      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-      for (uint32_t spins = 0;; ++spins) {
-        if (pend_count == 0 && r_left && (r_home || !m_left)) {  // claim a reprojection chunk
-          const uint32_t t = atomicAdd(&sync->r_ticket, kFusedReprojChunk);
-          if (t < r_total) {
-            pend_first = t;
-            pend_count = r_total - t < kFusedReprojChunk ? r_total - t : kFusedReprojChunk;
-          } else {
-            r_left = false;
-          }
-        }
-        if (pend_count) {  // ready when the frames it touches are filtered
-          const uint32_t f0 = pend_first / r_per_frame, f1 = (pend_first + pend_count - 1) / r_per_frame;
-          bool ready = true;
-          for (uint32_t f = f0; f <= f1; ++f)
-            ready = ready && __hip_atomic_load(&sync->done[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= m_per_frame;
-          if (ready) {
-            kind = 2, first = pend_first, count = pend_count, pend_count = 0;
-            break;
-          }
-        }
-        if (m_left) {
-          const uint32_t t = atomicAdd(&sync->m_ticket, kFusedMedianChunk);
-          if (t < m_total) {
-            kind = 1, first = t, count = m_total - t < kFusedMedianChunk ? m_total - t : kFusedMedianChunk;
-            break;
-          }
-          m_left = false;
-          continue;
-        }
-        if (!pend_count && !r_left) break;  // both queues are empty: finished
-        // a claimed chunk whose frames other blocks are still filtering: wait (bounded by time)
-        __builtin_amdgcn_s_sleep(8);
-        if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > uint64_t(spin_ticks)) {
-          kind = 3;  // give up: the launch is broken (a filter block died).  The chunk stays unwritten and
-          if (counts) {  // its frames say so in-band, like the single-pass compaction
-            const uint32_t f0 = pend_first / r_per_frame, f1 = (pend_first + pend_count - 1) / r_per_frame;
-            for (uint32_t f = f0; f <= f1; ++f)
-              __hip_atomic_store(counts + f, kCountTimedOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          break;
-        }
-      }
-      s_cmd[0] = kind, s_cmd[1] = first, s_cmd[2] = count;
-    }
-    __syncthreads();
-    const uint32_t kind = s_cmd[0], first = s_cmd[1], count = s_cmd[2];
-    __syncthreads();
-    if (kind == 0 || kind == 3) break;
-    if (kind == 1) {
-      // ---- median tiles first .. first+count-1 (frame-major, then rows of tiles) ------------------------
-      uint32_t f_run = 0xffffffffu, n_run = 0;
-      for (uint32_t t = first; t < first + count; ++t) {
-        const uint32_t f = t / m_per_frame, b = t - f * m_per_frame;
-        const uint32_t ty = b / ma.tiles_x, tx = b - ty * ma.tiles_x;
-        const int c0 = int(ma.out_x0) + int(tx) * S::TW, y0 = int(ma.out_y0) + int(ty) * S::TH;
-        if (f != f_run) {
-          // the chunk crossed into the next frame: count the finished part (every wave drained its stores in
-          // median_tile and passed the barrier that follows each tile)
-          if (n_run && tid == 0)
-            __hip_atomic_fetch_add(&sync->done[f_run], n_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          f_run = f, n_run = 0;
-        }
-#ifdef D2PC_FUSED_DIAG_PLAIN_STORES  // diagnosis only (results are then not guaranteed): the filter's bytes as plain stores
-        median_tile<KS, false>(src + uint64_t(f) * ma.src_frame_stride, med + uint64_t(f) * ma.dst_frame_stride, ma, c0, y0,
-                               s_pair, tid);
-#else
-        median_tile<KS, true>(src + uint64_t(f) * ma.src_frame_stride, med + uint64_t(f) * ma.dst_frame_stride, ma, c0, y0,
-                              s_pair, tid);
-#endif
-        __syncthreads();  // s_pair is rebuilt by the next tile
-        ++n_run;
-      }
-      if (tid == 0) __hip_atomic_fetch_add(&sync->done[f_run], n_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      // ---- reprojection tiles: k_reproject_pack's arithmetic with coherent 8-bit loads --------------------
-#ifdef D2PC_FUSED_DIAG_NO_REPROJ  // diagnosis only: reprojection chunks are claimed and dropped
-      for (uint32_t t = first; t < first; ++t) {
-#else
-      for (uint32_t t = first; t < first + count; ++t) {
-#endif
-        const uint32_t f = t / r_per_frame;
-        const uint32_t lt = t - f * r_per_frame;
-        const uint8_t *fin = med + uint64_t(f) * g.in_frame_stride;
-        float4 *fout = out + uint64_t(f) * g.out_frame_stride;
-        const uint32_t base = lt * RTILE;
-        // one batch of four slots at a time -- its loads first, then its points; coordinates are formed again per
-        // slot rather than kept: the block must stay within the filter's register budget, or the filter loses
-        // resident waves
-#pragma unroll
-        for (int b4 = 0; b4 < PXT / 4; ++b4) {
-          float d[4];
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const uint32_t i = base + uint32_t(b4) * RBATCH + wave * 256u + uint32_t(s4) * 64u + lane;
-            const uint32_t v = fdiv(i, g.div_roi_w);
-            const uint32_t off = (v + g.border) * g.row_stride + (i - v * g.roi_w + g.border);
-            d[s4] = load_u8_coherent(fin, off < g.last_off ? off : g.last_off, g.scale);
-          }
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const uint32_t i = base + uint32_t(b4) * RBATCH + wave * 256u + uint32_t(s4) * 64u + lane;
-            const uint32_t v = fdiv(i, g.div_roi_w);
-            float X, Y, Z;
-            reproject(Q, i - v * g.roi_w + g.border, v + g.border, d[s4], X, Y, Z);
-            if (i < g.roi_n) store_point<D2PC_STORE_NT != 0>(fout, i, X, Y, Z);
-            if (s4 & 1) __builtin_amdgcn_sched_barrier(0);  // two division chains interleaved at a time
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (counts && lt == 0 && tid == 0) counts[f] = g.roi_n;
-      }
-    }
-  }
-}
-
-// --------------------------------------------------------------------------
 // K1g: the callback body TILE BY TILE -- bit-sliced k x k median of a 256 x 32 tile of the inset ROI
 // (d2pc_median_bs_tile.hpp, cpp:55-57) and, from the filtered bytes still in LDS, the tile's points
 // (cpp:60-85, PARITY).  No hand-off between blocks and no filtered image in memory: the VALU-bound filter
 // and the store stream of the reprojection overlap because the chip's ~770 resident blocks are at
-// different stages at any time.  (k_callback_fused above tried the same overlap with two roles and
-// cross-block hand-offs, and lost.)
+// different stages at any time.  (An earlier form -- one persistent kernel whose blocks switched between
+// filter tiles and reprojection tiles, handing frames over through sc1 stores and loads -- was 1.4x SLOWER
+// than two launches and has been removed: DESIGN.md section 9.)
 //  * 8-bit input has 256 disparities, and with stereoRectify's Q (QK_STEREO) W = a*d + b does not depend on
 //    the pixel: every block evaluates 1/W and Z once per byte value (one division per THREAD) into LDS, and a
 //    pixel costs two fp64 additions, two multiplications and two casts -- the same operations on the same
@@ -1512,31 +1335,6 @@ static hipError_t dispatch(const LaunchArgs &a, bool compact) {
     case 16: return dispatch_q<16>(a, compact);
   }
   return hipErrorInvalidValue;
-}
-
-size_t fused_sync_bytes(uint32_t n_frames) { return sizeof(FusedSync) + size_t(n_frames) * sizeof(uint32_t); }
-
-// The fused callback body: 11 x 11 median + PARITY reprojection of 8-bit frames (the reference's constants);
-// other window sizes / modes take the two launches.
-hipError_t launch_callback_fused(const LaunchArgs &a, MedianArgs m, const void *src, void *med, int ksize, void *sync,
-                                 uint32_t blocks, uint32_t spin_ticks) {
-  if (ksize != 11 || a.pxt != 8 || a.dtype != DT_U8) return hipErrorInvalidValue;
-  using S = MedianShape<11>;
-  m.tiles_x = (m.out_w + S::TW - 1) / S::TW;
-  m.tiles_y = (m.out_h + S::TH - 1) / S::TH;
-  const size_t nb = fused_sync_bytes(m.n_frames);
-  const uint32_t n16 = uint32_t((nb + 15) / 16);
-  hipLaunchKernelGGL(k_state_clear, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(sync), n16);
-  const uint32_t rtile = uint32_t(S::THREADS) * 8u, r_per_frame = (a.geom.roi_n + rtile - 1) / rtile;
-  if (a.q_kind == QK_STEREO)
-    hipLaunchKernelGGL((k_callback_fused<11, QK_STEREO, 8>), dim3(blocks), dim3(S::THREADS), 0, a.stream,
-                       static_cast<const uint8_t *>(src), static_cast<uint8_t *>(med), static_cast<float4 *>(a.out_points),
-                       a.counts, static_cast<FusedSync *>(sync), m, a.geom, make_qarg<QK_STEREO>(a), r_per_frame, spin_ticks);
-  else
-    hipLaunchKernelGGL((k_callback_fused<11, QK_GENERAL, 8>), dim3(blocks), dim3(S::THREADS), 0, a.stream,
-                       static_cast<const uint8_t *>(src), static_cast<uint8_t *>(med), static_cast<float4 *>(a.out_points),
-                       a.counts, static_cast<FusedSync *>(sync), m, a.geom, make_qarg<QK_GENERAL>(a), r_per_frame, spin_ticks);
-  return hipGetLastError();
 }
 
 hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src, int ksize) {

@@ -89,11 +89,6 @@ bool tile_shape_supported(int pxt);
 uint32_t frame_state_stride(uint32_t tiles_per_frame);
 size_t compact_state_bytes(const Geom &g);
 hipError_t launch_parity(const LaunchArgs &a);
-// fused callback body (median 11 + PARITY reprojection of 8-bit frames in one persistent kernel); `sync` holds
-// fused_sync_bytes(n_frames) rounded up to 16, `m` carries the median's geometry incl. the output rectangle
-size_t fused_sync_bytes(uint32_t n_frames);
-hipError_t launch_callback_fused(const LaunchArgs &a, MedianArgs m, const void *src, void *med, int ksize, void *sync,
-                                 uint32_t blocks, uint32_t spin_ticks);
 // tile-fused callback body (bit-sliced k x k median + PARITY reprojection of the tile from LDS;
 // k_callback_bs): `m` carries the filter's geometry with the output rectangle = the ROI of a.geom; a.out_points,
 // a.out_index (nullable), a.counts (nullable), a.q*, a.stream as in launch_parity

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const ui
   b -= f * a.tiles_x * a.tiles_y;
   const uint32_t ty = b / a.tiles_x, tx = b - ty * a.tiles_x;
   const int c0 = int(a.out_x0) + int(tx) * S::TW, y0 = int(a.out_y0) + int(ty) * S::TH;
-  median_tile<KS, false>(src + uint64_t(f) * a.src_frame_stride, dst + uint64_t(f) * a.dst_frame_stride, a, c0, y0, s_pair,
+  median_tile<KS>(src + uint64_t(f) * a.src_frame_stride, dst + uint64_t(f) * a.dst_frame_stride, a, c0, y0, s_pair,
                          threadIdx.x);
 }
 

@@ -1,5 +1,4 @@
-// d2pc_median_tile.hpp -- the tile body of the median kernel (d2pc_median.hip), shared with the fused
-// callback kernel (d2pc_kernels.hip).
+// d2pc_median_tile.hpp -- the tile body of the per-pixel median kernel (d2pc_median.hip).
 //
 // d2pc_median.hip -- k x k median of an 8-bit image on gfx950 (k odd, <= 11),
 // BORDER_REPLICATE: the device form of cv::medianBlur(img, out, 11) at
@@ -61,11 +60,8 @@ struct MedianShape {
 };
 
 // One TW x 64 output tile at (c0, y0) of one frame.  Called by EVERY thread of the block (it contains the
-// block barrier); threads tid >= MedianShape<KS>::THREADS only take part in the barriers (the fused callback
-// kernel runs it in 256-thread blocks).  COHERENT: results are stored with agent-scope (sc1) byte stores and
-// drained before the function returns, so that another block -- possibly on another XCD, whose L2 is not
-// coherent with this one -- can read them with sc1 loads once it has seen the caller's completion counter.
-template <int KS, bool COHERENT>
+// block barrier); threads tid >= MedianShape<KS>::THREADS only take part in the barriers.
+template <int KS>
 __device__ __forceinline__ void median_tile(const uint8_t *__restrict__ fsrc, uint8_t *__restrict__ fdst,
                                             const MedianArgs &a, const int c0, const int y0,
                                             uint32_t (&s_pair)[MedianShape<KS>::LDS_WORDS], const uint32_t tid) {
@@ -208,8 +204,7 @@ __device__ __forceinline__ void median_tile(const uint8_t *__restrict__ fsrc, ui
 #pragma unroll
       for (int q = 0; q < NPX; ++q)
         if (ox + uint32_t(q) < a.out_x0 + a.out_w) {
-          if constexpr (COHERENT) __hip_atomic_store(o + q, uint8_t(255 + acc[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else o[q] = uint8_t(255 + acc[q]);
+          o[q] = uint8_t(255 + acc[q]);
         }
     }
     // the next item, THREADS further on
@@ -217,7 +212,6 @@ __device__ __forceinline__ void median_tile(const uint8_t *__restrict__ fsrc, ui
     x += uint32_t(NPX) * (uint32_t(S::THREADS) % TWP);
     if (x >= uint32_t(S::TW)) x -= uint32_t(S::TW), ++y;
   }
-  if constexpr (COHERENT) __builtin_amdgcn_s_waitcnt(0);  // every store of the tile has left this wave (vmcnt 0)
 }
 
 }  // namespace d2pc

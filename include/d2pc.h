@@ -299,14 +299,14 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
  * (profiles/r02_median_bitsliced.txt).  Everything else -- COMPACT mode, small
  * launches -- is the filter launch followed by the reprojection
  * launch.  The results are the same bytes either way.
- * Tuning "callback_fused": 2 (default) as described; 0 always two launches; 1 an
- * earlier attempt kept for the record: one persistent kernel whose blocks switch
- * between filter tiles and reprojection tiles and hand frames over in-kernel
- * (1.4x slower than two launches: DESIGN.md section 9).  "callback_chunks"
- * (default 1 = off) cuts a two-launch batch into chunks pipelined over two
- * internal streams: the two kernels side by side finish only 8-15 % sooner than
- * back to back and every cross-stream dependency costs ~20 us, so it ranged from
- * +8 % to -10 % (profiles/r02_callback_overlap.txt).
+ * Tuning "callback_fused": 1 (default) as described; 0 always two launches.
+ * (Round 2 also built this overlap as ONE persistent kernel whose blocks switched
+ * between filter tiles and reprojection tiles and handed frames over in-kernel;
+ * it was 1.4x slower than two launches and has been removed: DESIGN.md section 9.)
+ * "callback_chunks" (default 1 = off) cuts a two-launch batch into chunks
+ * pipelined over two internal streams: the two kernels side by side finish only
+ * 8-15 % sooner than back to back and every cross-stream dependency costs ~20 us,
+ * so it ranged from +8 % to -10 % (profiles/r02_callback_overlap.txt).
  * In the two-launch form the filtered frames live in context-owned scratch
  * (grown on demand, so the first call of a size is not capturable; under stream
  * capture the call runs in order on `stream`); the one-kernel form needs none.
@@ -463,7 +463,7 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
  * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
  * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
- * "callback_fused" (0, 1 or 2, see d2pc_process_mono_device; default 2),
+ * "callback_fused" (0/1, see d2pc_process_mono_device; default 1),
  * "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process / d2pc_process_mono8
  * without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose per launch,
  * 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes). */

@@ -303,38 +303,6 @@ def test_process_mono_device_rejects_bad_arguments_and_runs_in_order_under_captu
         assert_points_close(res[f][0], want, max_ulp=1, what=f"captured frame {f}")
 
 
-@pytest.mark.parametrize("shape", [(5, 480, 752), (3, 1080, 1920), (2, 131, 203), (9, 300, 408)])
-def test_fused_callback_kernel_matches_the_two_launches_and_the_oracle(shape):
-    """k_callback_fused: 11 x 11 median over the ROI and PARITY reprojection of an 8-bit batch in ONE persistent
-    kernel (blocks switch between filter chunks and reprojection chunks; hand-off through sc1 stores/loads).
-    Off by default (it is slower than the two launches: a recorded negative result), kept correct: bit-identical to
-    the filter launch followed by the reprojection launch, relaunched several times."""
-    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
-    q = d2pc.make_q()
-    n, h, w = shape
-    rng = np.random.default_rng(n * h + w)
-    imgs = rng.integers(0, 256, size=(n, h, w)).astype(np.uint8)
-    src = torch.from_numpy(imgs).cuda()
-    res = {}
-    with d2pc.Context(q=q) as ctx:
-        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8)
-        s = torch.cuda.current_stream().cuda_stream
-        for fused in (1, 0):
-            ctx.set_tuning("callback_fused", fused)
-            for _ in range(3):
-                b.points.fill_(0)
-                b.counts.fill_(0)
-                ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125, b.points.data_ptr(),
-                                        None, b.stride, b.counts.data_ptr(), s)
-            res[fused] = b.results()
-            assert not np.any(b.counts.cpu().numpy().view(np.uint32) == 0xFFFFFFFF)
-    for f in range(n):
-        want = oracle.reproject(oracle.median_u8(imgs[f], 11), q, border=40, scale=0.125)
-        assert len(res[1][f][0]) == len(want)
-        assert np.array_equal(res[1][f][0].view(np.uint32), res[0][f][0].view(np.uint32)), f"frame {f}: fused != two launches"
-        assert_points_close(res[1][f][0], want, max_ulp=1, rel=1e-5, what=f"fused frame {f}")
-
-
 @pytest.mark.parametrize("general_q", [0, 1])
 @pytest.mark.parametrize("k,shape,border,scale", [(11, (3, 480, 752), 40, 0.125), (11, (2, 131, 203), 7, 0.37),
                                                   (9, (2, 300, 408), 40, 0.125), (11, (1, 97, 600), 0, 1.0),
@@ -358,7 +326,7 @@ def test_tile_fused_callback_kernel_matches_the_two_launches_and_the_oracle(gene
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
         s = torch.cuda.current_stream().cuda_stream
-        for fused in (2, 0):
+        for fused in (1, 0):
             ctx.set_tuning("callback_fused", fused)
             for _ in range(2):
                 b.points.fill_(0)
@@ -369,12 +337,12 @@ def test_tile_fused_callback_kernel_matches_the_two_launches_and_the_oracle(gene
             torch.cuda.synchronize()
             res[fused] = (b.points.cpu().numpy().copy(), b.index.cpu().numpy().copy(), b.counts.cpu().numpy().copy())
         ctx.check_async_error()
-    for a, c in zip(res[2], res[0]):
+    for a, c in zip(res[1], res[0]):
         assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), "tile-fused kernel differs from the two launches"
-    pts = res[2][0].reshape(n, -1, 4)
+    pts = res[1][0].reshape(n, -1, 4)
     for f in range(n):
         want = oracle.reproject(oracle.median_u8(np.ascontiguousarray(imgs[f, :, :w]), k), q, border=border, scale=scale)
-        assert res[2][2].view(np.uint32)[f] == len(want)
+        assert res[1][2].view(np.uint32)[f] == len(want)
         assert_points_close(pts[f][:len(want)], want, max_ulp=1, rel=1e-5, what=f"frame {f}")
 
 
@@ -391,14 +359,14 @@ def test_tile_fused_callback_kernel_with_degenerate_scales(scale):
     with d2pc.Context(q=d2pc.make_q(), border=7) as ctx:
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8)
-        for fused in (2, 0):
+        for fused in (1, 0):
             ctx.set_tuning("callback_fused", fused)
             b.points.fill_(0)
             ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, scale, b.points.data_ptr(), None,
                                     b.stride, b.counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             res[fused] = b.points.cpu().numpy().view(np.uint32).copy()
-    assert np.array_equal(res[2], res[0])
+    assert np.array_equal(res[1], res[0])
 
 
 def test_tile_fused_callback_kernel_is_capturable_without_a_warm_up_call():

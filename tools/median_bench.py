@@ -52,7 +52,7 @@ for (w, h, n) in ((752, 480, 64), (1920, 1080, 16), (3840, 2160, 16)):
         b.launch(scale=0.125)
     us = t(body)
     us_r = t(lambda: b.launch(scale=0.125))
-    for fused in (2, 1, 0):  # tile-fused bit-sliced kernel, persistent two-role kernel, two launches
+    for fused in (1, 0):  # one kernel tile by tile (k_callback_bs), two launches
         ctx.set_tuning("callback_fused", fused); ctx.set_tuning("callback_chunks", 1)
         uf = t(lambda: ctx.process_mono_device(raw.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125,
                                                b.points.data_ptr(), None, b.stride, b.counts.data_ptr(), s))
