@@ -48,9 +48,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifndef D2PC_ONEPASS_STORE_NT
 #define D2PC_ONEPASS_STORE_NT 0
 #endif
-#ifndef D2PC_ONEPASS_ROWS
-#define D2PC_ONEPASS_ROWS 0
-#endif
 #ifndef D2PC_SCATTER_STORE_NT
 #define D2PC_SCATTER_STORE_NT 1
 #endif
@@ -936,73 +933,6 @@ __device__ __forceinline__ void tile_scatter_lean(const QArg<QK> &Q, const Geom 
   }
 }
 
-// EXPERIMENT (D2PC_ONEPASS_ROWS, off by default): the survivors of a wave's four slots of a batch are compacted in a
-// wave-private LDS strip and leave as rows of 64 consecutive points whose boundaries sit on 64-byte lines of the
-// OUTPUT (row 0 is short by the run's misalignment), so that every line of the run except its two ends is written by
-// ONE full request; indices likewise on their own 64-byte grid.  The judge's round-1 suggestion, without the 1-KiB
-// windows of the variant round 1 rejected.  Stereo-structured Q, tiles without a sliver only.
-template <int PXT, bool IDX>
-__device__ __forceinline__ void tile_scatter_rows(const QArg<QK_STEREO> &Q, const Geom &g, const float (&d)[PXT],
-                                                  const uint32_t *cell_excl, uint32_t prefix, uint32_t base, uint32_t wave,
-                                                  uint32_t lane, uint64_t fout, uint64_t fidx, float *pstrip, uint32_t *istrip) {
-  using gv4f = __attribute__((address_space(1))) v4f;
-  using gu32 = __attribute__((address_space(1))) uint32_t;
-  const uint32_t i0 = base + wave * 256u + lane;
-  const uint32_t lim = base + uint32_t(kBlock * PXT) > g.roi_n ? g.roi_n : 0xffffffffu;
-  uint32_t uus[PXT], vvs[PXT];
-  tile_coords<PXT>(uus, vvs, g, base, wave, lane);
-#pragma unroll
-  for (int b = 0; b < PXT / 4; ++b) {
-    uint32_t run = 0;  // survivors of the batch so far (wave-uniform)
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int k = b * 4 + s4;
-      const uint32_t uu = uus[k], vv = vvs[k];
-      const uint32_t i = i0 + uint32_t(b) * 1024u + uint32_t(s4) * 64u;
-      const double nw = stereo_nw(Q, d[k]);
-      const bool ok = int(finite_nonzero(nw)) & int(fabs(nw) >= Q.s.w_safe) & int(!(d[k] <= g.min_disparity)) & int(i < lim);
-      const uint64_t m = __ballot(ok);
-      if (m != 0) {
-        const double iw = 1.0 / nw;
-        const v4f p = {float((double(uu) + Q.s.cx) * iw), float((double(vv) + Q.s.cy) * iw),
-                       big_z_rule(d[k], float(Q.s.f * iw)), 1.0f};
-        const uint32_t r = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), run));
-        if (ok) {
-          *reinterpret_cast<v4f *>(pstrip + r * 4u) = p;
-          if constexpr (IDX) istrip[r] = vv * g.width + uu;
-        }
-        run += uint32_t(__popcll(m));
-      }
-    }
-    if (run == 0) continue;
-    const uint32_t p0 = prefix + cell_excl[cell_index(b * 4, wave)];  // output position of the batch's first survivor
-    {
-      const uint32_t a = p0 & 3u;  // points into a 64-byte line of the output
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        if (uint32_t(j) * 64u >= run + a) break;  // wave-uniform
-        const uint32_t r = uint32_t(j) * 64u + lane - a;  // (wraps for the lanes in front of the run)
-        const uint32_t pos = p0 + r;
-        if (r < run && pos < g.roi_n) {
-          const v4f p = *reinterpret_cast<const v4f *>(pstrip + r * 4u);
-          if (D2PC_ONEPASS_STORE_NT) __builtin_nontemporal_store(p, (gv4f *)(fout + (uint64_t(pos) << 4)));
-          else *(gv4f *)(fout + (uint64_t(pos) << 4)) = p;
-        }
-      }
-    }
-    if constexpr (IDX) {
-      const uint32_t a = p0 & 15u;  // indices into a 64-byte line
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        if (uint32_t(j) * 64u >= run + a) break;
-        const uint32_t r = uint32_t(j) * 64u + lane - a;
-        const uint32_t pos = p0 + r;
-        if (r < run && pos < g.roi_n) *(gu32 *)(fidx + (uint64_t(pos) << 2)) = istrip[r];
-      }
-    }
-  }
-}
-
 // A worker wave's disparities of one tile in flight: the raw 16-byte row pieces (VEC) or the decoded
 // slot values.  Issue and finish are separate so that the loads fly across the scatter of an older tile
 // and the block barriers; finish() turns the pieces into the slot layout through the wave's LDS strip.
@@ -1066,12 +996,6 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
   constexpr uint32_t kWaveStage = uint32_t(PXT / 4) * 256u, kStage = (kBlock / 64) * kWaveStage;
   __shared__ float s_tile[4 * kStage];
   float *const my_tile = s_tile + (wave < kBlock / 64 ? wave : 0u) * kWaveStage;
-#if D2PC_ONEPASS_ROWS
-  __shared__ float s_pstrip[(kBlock / 64) * 1024];    // 256 points x 16 B per worker wave
-  __shared__ uint32_t s_istrip[(kBlock / 64) * 256];  // 256 indices per worker wave
-  float *const my_pstrip = s_pstrip + (wave < kBlock / 64 ? wave : 0u) * 1024u;
-  uint32_t *const my_istrip = s_istrip + (wave < kBlock / 64 ? wave : 0u) * 256u;
-#endif
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
   uint32_t spin_acc = 0;
 #ifdef D2PC_DIAG
@@ -1170,17 +1094,6 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
           stage_read<PXT>(dq, my_tile + ((it + 2u) & 3u) * kStage, lane);  // counted in iteration it - 2
           const uint32_t prefix = s_prefix[slot];
           const uint32_t *cell_base = s_excl[ring2];
-#if D2PC_ONEPASS_ROWS == 2  // control build: the same LDS footprint (hence residency), the direct stores
-          if (prefix == 0xfffffff0u) my_pstrip[lane] = float(my_istrip[lane]);
-#endif
-#if D2PC_ONEPASS_ROWS == 1
-          if (QK == QK_STEREO && !qexact && s_total[ring2] != TILE) {  // a tile with holes: rows through LDS
-            if constexpr (QK == QK_STEREO) {
-              if (fidx) tile_scatter_rows<PXT, true>(Q, g, dq, cell_base, prefix, prev2 * TILE, wave, lane, vout, vidx, my_pstrip, my_istrip);
-              else tile_scatter_rows<PXT, false>(Q, g, dq, cell_base, prefix, prev2 * TILE, wave, lane, vout, vidx, my_pstrip, my_istrip);
-            }
-          } else
-#endif
           if (qexact) {  // (a tile with a sliver, or a general Q: rare / not the calibrated case -- one code copy)
             if (fidx) tile_scatter_lean<QK, PXT, true, true>(Q, g, dq, cell_base, prefix, prev2 * TILE, wave, lane, vout, vidx);
             else tile_scatter_lean<QK, PXT, true, false>(Q, g, dq, cell_base, prefix, prev2 * TILE, wave, lane, vout, vidx);
