@@ -417,11 +417,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
       } else {
         reproject(Q, x, y, __fmul_rn(float(raw[q]), g.scale), X, Y, Z);
       }
-#ifdef D2PC_CB_BS_DIAG_NOSTORE  // (timing diagnosis: the points are computed and dropped)
-      if (x < x_end && X == 1.25f && Y == 2.5f && Z == 7.75f) {
-#else
       if (x < x_end) {
-#endif
         store_point<D2PC_STORE_NT != 0>(fout, row_point + x, X, Y, Z);
         if (fidx) store_index(fidx, row_point + x, y * g.width + x);
       }
