@@ -156,6 +156,74 @@ def timed_steps(batch, steps, warmup, dist_sync):
     return t1 - t0, e0.elapsed_time(e1) / steps
 
 
+def timed_rounds(batch, n, warmup=2, floor_ms=100.0, min_rounds=5, max_rounds=400):
+    """Side measurements and spreads: ROUNDS of `n` back-to-back launches, every round between two HIP events
+    on the launch stream, as many rounds as it takes for the GPU time to sum to >= floor_ms (one short probe
+    round sizes the run; then everything is enqueued with ONE synchronisation at the end, so no round starts
+    on an idle device).  Returns the per-round averages in ms per launch."""
+    for _ in range(warmup):
+        batch.launch()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        batch.launch()
+    b.record()
+    torch.cuda.synchronize()
+    probe = max(a.elapsed_time(b), 1e-3)
+    rounds = int(min(max_rounds, max(min_rounds, -(-floor_ms // probe))))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(rounds + 1)]
+    ev[0].record()
+    for r in range(rounds):
+        for _ in range(n):
+            batch.launch()
+        ev[r + 1].record()
+    torch.cuda.synchronize()
+    return [ev[r].elapsed_time(ev[r + 1]) / n for r in range(rounds)]
+
+
+def spread(ms):
+    """min / median / max of per-round averages (ms per launch)."""
+    s = sorted(ms)
+    return {"min": round(s[0], 4), "median": round(s[len(s) // 2], 4), "max": round(s[-1], 4), "rounds": len(s)}
+
+
+def device_calibration(ctx, batch):
+    """What THIS device gives kernels that only stream, measured in this run on the benchmark's own 2-GB output
+    buffer: a plain 16-B-per-lane fill, and a copy of its first half onto its second (GB/s = bytes read + written)."""
+    s = torch.cuda.current_stream().cuda_stream
+    nbytes = batch.points.numel() * 4 // 32 * 32
+    half = nbytes // 2
+    base = batch.points.data_ptr()
+
+    class _Fill:
+        def launch(self):
+            ctx.membench_fill(base, nbytes, s)
+
+    class _Copy:
+        def launch(self):
+            ctx.membench_copy(base, base + half, half, s)
+
+    f = spread(timed_rounds(_Fill(), 5))
+    c = spread(timed_rounds(_Copy(), 5))
+    return {"device_fill_GBs": round(nbytes / (f["median"] * 1e-3) / 1e9, 1),
+            "device_copy_GBs": round(2 * half / (c["median"] * 1e-3) / 1e9, 1),
+            "device_fill_ms": f, "device_copy_ms": c, "calibration_bytes": nbytes,
+            "calibration_what": "k_membench_fill over the bench's output buffer; k_membench_copy of its first half onto "
+                                "its second (bytes read + written); medians of >= 100 ms of rounds of 5 launches"}
+
+
+def compaction_counters(ctx):
+    """d2pc_compact_stats since the last reset, per tile (the single pass only)."""
+    st = ctx.compact_stats()
+    if not st["launches"]:
+        return None
+    t = max(st["tiles"], 1)
+    return {"launches": st["launches"], "tiles_per_launch": st["tiles"] // st["launches"],
+            "failed_polls_per_tile": round(st["failed_polls"] / t, 4),
+            "wait_us_per_tile": round(st["wait_us"] / t, 4), "timeouts": st["timeouts"],
+            "twopass_fallbacks": st["twopass_fallbacks"]}
+
+
 def cpu_baseline(q, border, budget_s=12.0):
     """The CPU restatement of cpp:63-85 (oracle, kind "port") on the same 4K
     workload, single thread like the reference's ros::spin(); bounded sample."""
@@ -381,6 +449,19 @@ def main():
             "read_component_GBs": round(4 * a.frames * batch.roi_n / (kernel_ms * 1e-3) / 1e9, 1),
         },
     }
+    if rank == 0 and world == 1:
+        # after the contract's timed region: how much the same launch moves on this device (rounds of `steps`
+        # launches until >= 100 ms), and what the device gives a plain fill / copy in this very run
+        sp = spread(timed_rounds(batch, a.steps, 0))
+        out["roofline"]["kernel_ms_spread"] = sp
+        out["roofline"]["frac_at_min_median_max_ms"] = [round(alg / (sp[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                        for k in ("min", "median", "max")]
+        cal = device_calibration(ctx, batch)
+        out["roofline"].update(cal)
+        out["roofline"]["achieved_over_device_fill"] = round(achieved / cal["device_fill_GBs"], 4)
+        out["roofline"]["achieved_over_device_copy"] = round(achieved / cal["device_copy_GBs"], 4)
+        if mode == d2pc.MODE_COMPACT:
+            out["roofline"]["compaction_counters"] = compaction_counters(ctx)
     if a.share_gpu:
         out["config"]["rehearsal_shared_gpu"] = True
     out["config"]["build"] = build_id()
@@ -400,10 +481,13 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_variants:  # side measurements only in the 1-GPU run
         variants = {}
+        n_side = max(a.steps // 4, 5)  # launches per round; rounds repeat until >= 100 ms (timed_rounds)
         for name, vmode, vborder, kind, idx in (
             ("parity_border0", d2pc.MODE_PARITY, 0, "uniform", False),
             ("compact_border40_all_valid", d2pc.MODE_COMPACT, 40, "uniform", False),
+            ("compact_border40_30pct_holes", d2pc.MODE_COMPACT, 40, "holes", False),
             ("compact_border40_30pct_holes_index", d2pc.MODE_COMPACT, 40, "holes", True),
+            ("compact_border40_all_valid_index", d2pc.MODE_COMPACT, 40, "uniform", True),
         ):
             c2 = d2pc.Context(device_id=local_rank, border=vborder, mode=vmode, q=q)
             b2 = DeviceBatch(c2, a.frames, H4K, W4K, want_index=idx, device=dev)
@@ -414,14 +498,18 @@ def main():
             b2.launch()
             torch.cuda.synchronize()
             npts = int(b2.counts.sum().item())
-            _, kms = timed_steps(b2, max(a.steps // 4, 5), 3, lambda: None)
+            if vmode == d2pc.MODE_COMPACT:
+                c2.compact_stats_reset()
+            sp = spread(timed_rounds(b2, n_side, 3))
+            kms = sp["median"]
             ab = algorithmic_bytes(b2, npts, idx)
             variants[name] = {"Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1),
                               "achieved_GBs": round(ab / (kms * 1e-3) / 1e9, 1),
                               "frac": round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "kernel_ms_avg": round(kms, 4), "points_per_step": npts}
+                              "kernel_ms_avg": kms, "kernel_ms_spread": sp, "points_per_step": npts}
             if vmode == d2pc.MODE_COMPACT:
                 c2.check_async_error()
+                variants[name]["compaction_counters"] = compaction_counters(c2)
             del b2
             c2.close()
         # config 3's own geometry: 1920x1080, ~30 % invalid (iid), COMPACT with indices -- one frame (the
@@ -435,12 +523,15 @@ def main():
             b2.launch()
             torch.cuda.synchronize()
             npts = int(b2.counts.sum().item())
-            _, kms = timed_steps(b2, max(a.steps // 2, 20), 5, lambda: None)
+            c2.compact_stats_reset()
+            sp = spread(timed_rounds(b2, max(a.steps // 2, 20), 5))
+            kms = sp["median"]
             ab = algorithmic_bytes(b2, npts, True)
             variants[name] = {"Mpixels_per_s": round(nfr * W3 * H3 / (kms * 1e-3) / 1e6, 1),
                               "achieved_GBs": round(ab / (kms * 1e-3) / 1e9, 1),
                               "frac": round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "ms_per_launch": round(kms, 4), "points_per_launch": npts,
+                              "ms_per_launch": kms, "ms_per_launch_spread": sp, "points_per_launch": npts,
+                              "compaction_counters": compaction_counters(c2),
                               "what": "config 3 geometry; " + ("k_compact_count + k_compact_scan + k_compact_scatter"
                                                                if nfr == 1 else "k_state_clear + k_compact_onepass")}
             c2.check_async_error()
@@ -465,20 +556,23 @@ def main():
                                      W4K * H4K, 11, s3)
                 b3.launch(scale=0.125)
 
-        _, kms = timed_steps(_Body(), max(a.steps // 2, 10), 5, lambda: None)
-        _, kms2 = timed_steps(_TwoLaunches(), max(a.steps // 2, 10), 5, lambda: None)
+        sp, sp2 = spread(timed_rounds(_Body(), n_side, 3)), spread(timed_rounds(_TwoLaunches(), n_side, 3))
+        kms, kms2 = sp["median"], sp2["median"]
         variants["callback_u8_median11_parity_border40"] = {
-            "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": round(kms, 4),
+            "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
+            "kernel_ms_spread": sp, "as_two_launches_ms_spread": sp2,
             "what": "d2pc_process_mono_device: k_callback_bs<11> (bit-sliced median of a tile + its points from LDS) per step",
             "as_two_launches_ms": round(kms2, 4),
             "as_two_launches_what": "k_median_bs_u8<11> over the inset ROI + k_reproject_pack<U8>"}
         b3.disp.copy_(raw)
-        _, kms = timed_steps(b3, max(a.steps // 4, 5), 3, lambda: None)
+        sp = spread(timed_rounds(b3, n_side, 3))
+        kms = sp["median"]
         ab = a.frames * b3.roi_n * 17
         variants["parity_u8_input_border40"] = {
             "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1),
             "achieved_GBs": round(ab / (kms * 1e-3) / 1e9, 1), "frac": round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "kernel_ms_avg": round(kms, 4), "what": "fused cpp:61 decode: 1 B read + 16 B written per pixel"}
+            "kernel_ms_avg": kms, "kernel_ms_spread": sp,
+            "what": "fused cpp:61 decode: 1 B read + 16 B written per pixel"}
         del b3
         c3.close()
         if not a.no_host_path:

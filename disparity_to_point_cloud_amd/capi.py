@@ -5,6 +5,7 @@ and nothing else.  The binding never computes points itself.
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -28,7 +29,8 @@ ABI_SYMBOLS = [
     "d2pc_pipeline_release", "d2pc_fuse_desc_init", "d2pc_fuse_device", "d2pc_crop_to_square",
     "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16", "d2pc_last_stage_times",
     "d2pc_median_roi_device", "d2pc_host_alloc", "d2pc_host_free", "d2pc_make_q_flavour",
-    "d2pc_process_mono_device",
+    "d2pc_process_mono_device", "d2pc_reserve_mono", "d2pc_release_graph_buffers", "d2pc_compact_stats",
+    "d2pc_compact_stats_reset", "d2pc_membench_fill", "d2pc_membench_copy",
 ]
 # d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
 (FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
@@ -84,28 +86,44 @@ class StageTimes(ctypes.Structure):
                 ("d2h_ms", ctypes.c_float), ("total_ms", ctypes.c_float)]
 
 
+class CompactStats(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("launches", ctypes.c_uint64),
+                ("tiles", ctypes.c_uint64), ("failed_polls", ctypes.c_uint64), ("wait_us", ctypes.c_uint64),
+                ("timeouts", ctypes.c_uint64), ("twopass_fallbacks", ctypes.c_uint64)]
+
+
 class PinnedBuffer:
     """Page-locked host memory from d2pc_host_alloc with a numpy view (d2pc_process* stores the cloud
-    straight into such a buffer).  Freed when the object is collected or close()d."""
+    straight into such a buffer).
+
+    The ALLOCATION belongs to the array, not to this object: `.array` (and every view or slice taken from
+    it) keeps the memory alive, and d2pc_host_free runs when the last of them is gone.  So
+    `out=PinnedBuffer(...).array` is safe, and close() / garbage collection of the PinnedBuffer only drop
+    this object's own reference."""
 
     def __init__(self, shape, dtype):
-        self._L = load_library()
+        lib = load_library()
         shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        self.ptr = self._L.d2pc_host_alloc(max(nbytes, 1))
+        self.ptr = lib.d2pc_host_alloc(max(nbytes, 1))
         if not self.ptr:
             raise MemoryError(f"d2pc_host_alloc({nbytes}) failed")
         buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(self.ptr)
+        # np.frombuffer keeps `buf` alive through the array's base chain; the finalizer hangs on `buf`
+        self._finalizer = weakref.finalize(buf, lib.d2pc_host_free, self.ptr)
+        self._finalizer.atexit = False  # at interpreter exit the HIP runtime may be gone already: leave it to the OS
         self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
-    def close(self):
-        if getattr(self, "ptr", None):
-            self.array = None
-            self._L.d2pc_host_free(self.ptr)
-            self.ptr = None
+    @property
+    def alive(self) -> bool:
+        """False once the memory has been handed back to d2pc_host_free."""
+        return self._finalizer.alive
 
-    def __del__(self):
-        self.close()
+    def close(self):
+        """Drop this object's reference.  The memory is freed now if no other view of `.array` exists,
+        otherwise when the last one is collected."""
+        self.array = None
+        self.ptr = None
 
 
 class D2pcError(RuntimeError):
@@ -202,6 +220,12 @@ def load_library():
                                         vp, ctypes.c_size_t, ctypes.c_size_t, vp]
     L.d2pc_crop_to_square.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)] * 3
     L.d2pc_check_async_error.argtypes = [vp]
+    L.d2pc_reserve_mono.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.d2pc_release_graph_buffers.argtypes = [vp]
+    L.d2pc_compact_stats.argtypes = [vp, ctypes.POINTER(CompactStats)]
+    L.d2pc_compact_stats_reset.argtypes = [vp]
+    L.d2pc_membench_fill.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    L.d2pc_membench_copy.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
     L.d2pc_set_tuning.argtypes = [vp, cp, ctypes.c_int]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
@@ -382,10 +406,33 @@ class Context:
     def check_async_error(self):
         self._check(self._L.d2pc_check_async_error(self._h))
 
+    def reserve_mono(self, dtype, width, height, n_frames=1):
+        self._check(self._L.d2pc_reserve_mono(self._h, dtype, width, height, n_frames))
+
+    def release_graph_buffers(self):
+        self._check(self._L.d2pc_release_graph_buffers(self._h))
+
+    def compact_stats(self) -> dict:
+        """d2pc_compact_stats: counters of the single-pass compaction since creation / the last reset."""
+        s = CompactStats()
+        s.struct_size = ctypes.sizeof(CompactStats)
+        self._check(self._L.d2pc_compact_stats(self._h, ctypes.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in CompactStats._fields_ if k not in ("struct_size", "reserved")}
+
+    def compact_stats_reset(self):
+        self._check(self._L.d2pc_compact_stats_reset(self._h))
+
+    def membench_fill(self, d_dst_ptr, nbytes, stream_ptr=None):
+        self._check(self._L.d2pc_membench_fill(self._h, d_dst_ptr, nbytes, stream_ptr))
+
+    def membench_copy(self, d_src_ptr, d_dst_ptr, nbytes, stream_ptr=None):
+        self._check(self._L.d2pc_membench_copy(self._h, d_src_ptr, d_dst_ptr, nbytes, stream_ptr))
+
     # -- hot path: host buffers (d2pc_process) ------------------------------
     def process(self, disp: np.ndarray, scale=1.0, want_index=False, capacity=None, out=None, out_index=None):
         """(H,W) numpy disparity -> ((n,4) float32 points[, (n,) uint32 index]).  `out` / `out_index`: caller
-        buffers to fill (e.g. PinnedBuffer(...).array, which the kernels then store into directly)."""
+        buffers to fill (e.g. PinnedBuffer(...).array, which the kernels then store into directly; the array
+        owns the pinned allocation, so no separate reference to the PinnedBuffer is needed)."""
         if disp.ndim != 2 or disp.strides[1] != disp.itemsize:
             raise ValueError("disp must be a 2-D array with contiguous rows")
         dt = _NP2DT.get(disp.dtype)

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -18,20 +19,30 @@
 
 using namespace d2pc;
 
-// One compaction-state buffer.  A COMPACT launch owns its buffer from the zeroing memset to its last
-// store, so launches that may overlap (different streams, a captured graph being replayed) never share one.
+// A device buffer that ONE stream's work owns at a time.  Two pools of them per context: the compaction state
+// (a COMPACT launch owns its buffer from the zeroing kernel to its last store) and the scratch of
+// d2pc_process_mono_device's two-launch form (filtered frames in `p`, rescaled mono16 frames in `p2`).  Launches
+// that may overlap (different streams, a captured graph being replayed) never share one.
 struct StateBuf {
-  void *p = nullptr;
-  size_t cap = 0;
+  void *p = nullptr;   size_t cap = 0;
+  void *p2 = nullptr;  size_t cap2 = 0;  // callback scratch only
   hipStream_t stream = nullptr;  // stream of the last launch that used it (valid when `bound`)
   bool bound = false;
   hipEvent_t done = nullptr;     // recorded behind that launch (not while capturing)
   bool pending = false;          // `done` was recorded and has not been seen complete yet
   int algo = 0;                  // algorithm of that launch: 2 = single pass (its header holds the timeout flag)
   bool captured = false;         // a stream capture baked the pointer into a graph: never freed, moved or shared
+                                 // until d2pc_release_graph_buffers
   unsigned long long capture_id = 0;
 };
-constexpr int kMaxStateBufs = 8;
+// Buffers that do not belong to a captured graph: at most this many per pool (a ninth stream waits for one);
+// buffers owned by graphs come on top, so captures can never starve the eager launches of a context.
+constexpr int kMaxEagerBufs = 8;
+struct BufPool {
+  std::vector<StateBuf *> bufs;  // pointers: a buffer's address is stable while the vector grows
+  size_t reserve = 0, reserve2 = 0;  // d2pc_reserve / d2pc_reserve_mono: every buffer is at least this large
+  const char *what = "";
+};
 
 // One frame in flight on the pipelined host path (d2pc_pipeline_*).
 struct PipeSlot {
@@ -78,8 +89,10 @@ struct d2pc_ctx {
   int host_direct_read = 1;      // synchronous host entry points: a PINNED input frame is read by the first kernel in place
   int median_algo = 0;           // MedianArgs::algo: 0 choose per launch, 1 per-pixel select, 2 bit-sliced (k = 9, 11)
   // device scratch
-  StateBuf states[kMaxStateBufs];  // compaction state, one per stream with COMPACT work in flight
-  size_t state_reserve = 0;        // d2pc_reserve: every buffer is at least this large
+  BufPool states;                  // compaction state, one buffer per stream with COMPACT work in flight
+  BufPool cb_scratch;              // d2pc_process_mono_device, two-launch form: one scratch per stream in flight
+  // production counters (d2pc_compact_stats): reset by d2pc_compact_stats_reset
+  uint64_t n_twopass_fallbacks = 0;  // synchronous host calls that reran a timed-out single pass with the two-pass form
   void *d_in = nullptr;      size_t in_cap = 0;
   void *d_out = nullptr;     size_t out_cap = 0;
   void *d_idx = nullptr;     size_t idx_cap = 0;
@@ -87,6 +100,9 @@ struct d2pc_ctx {
   void *d_cvt = nullptr;     size_t cvt_cap = 0;   // mono16 -> mono8 (cpp:50)
   uint32_t *d_counts = nullptr;
   uint32_t *h_counts = nullptr;  // pinned
+  CompactStats *d_stats = nullptr;  // single-pass counters, accumulated by k_state_clear (d2pc_compact_stats)
+  CompactStats stats_host{};        // counters of state buffers that were freed before a later launch folded them
+  int membench_blocks_per_cu = 8;
   // d2pc_process_mono_device: two internal streams + scratch for the filtered frames
   int cb_fused = 1;              // d2pc_process_mono_device, PARITY: median + points in one kernel, tile by tile (k_callback_bs:
                                  // bit-sliced median, the tile's points from LDS) when the launch is large enough for the
@@ -95,8 +111,8 @@ struct d2pc_ctx {
                                  // overlapping did not pay reliably: profiles/r02_callback_overlap.txt)
   hipStream_t cb_stream_m = nullptr, cb_stream_r = nullptr;
   std::vector<hipEvent_t> cb_events;
-  void *d_cb_med = nullptr;  size_t cb_med_cap = 0;
-  void *d_cb_cvt = nullptr;  size_t cb_cvt_cap = 0;
+  hipEvent_t cb_overlap_done = nullptr;  // the chunked-overlap form shares the two streams above: calls are serialised
+  bool cb_overlap_pending = false;
   // pipelined host path
   PipeSlot slots[8];
   int pipe_depth = 0;
@@ -249,71 +265,94 @@ bool state_idle(StateBuf &b) {
   return false;
 }
 
-int state_alloc(d2pc_ctx *ctx, StateBuf &b, size_t need) {
-  if (need < ctx->state_reserve) need = ctx->state_reserve;
+int state_alloc(d2pc_ctx *ctx, const BufPool *pool, StateBuf &b, size_t need, size_t need2 = 0) {
+  if (pool && need < pool->reserve) need = pool->reserve;
+  if (pool && need2 < pool->reserve2) need2 = pool->reserve2;
   if (!b.done) D2PC_HIP(ctx, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
-  if (b.p && b.cap >= need) return D2PC_OK;
-  if (b.p) {
-    if (b.pending) D2PC_HIP(ctx, hipEventSynchronize(b.done));  // its last launch still reads and writes it
+  if (b.cap >= need && b.cap2 >= need2) return D2PC_OK;
+  if ((b.p || b.p2) && b.pending) {
+    D2PC_HIP(ctx, hipEventSynchronize(b.done));  // its last launch still reads and writes it
     b.pending = false;
   }
-  return grow(ctx, &b.p, &b.cap, need);
+  if (b.p && b.algo == 2 && b.cap < need && b.cap >= sizeof(StateHeader)) {
+    // a compaction state about to be replaced: keep the counters its last single-pass launch left in the header
+    StateHeader h;
+    D2PC_HIP(ctx, hipMemcpy(&h, b.p, sizeof h, hipMemcpyDeviceToHost));
+    ctx->stats_host.launches += h.launches;
+    ctx->stats_host.tiles += h.tiles;
+    ctx->stats_host.failed_polls += h.failed_polls;
+    ctx->stats_host.wait_ticks += h.wait_ticks;
+    ctx->stats_host.timeouts += h.launches && h.timeout ? 1 : 0;
+    b.algo = 0;
+  }
+  int st = grow(ctx, &b.p, &b.cap, need);
+  if (st == D2PC_OK && need2) st = grow(ctx, &b.p2, &b.cap2, need2);
+  return st;
 }
 
-// The compaction state for a launch of `need` bytes on `stream`.
+int eager_bufs(const BufPool &pool) {
+  int n = 0;
+  for (const StateBuf *b : pool.bufs) n += b->captured ? 0 : 1;
+  return n;
+}
+
+// A buffer of the pool for work of `need` (+ `need2`) bytes on `stream`.
 //  * launches on ONE stream are ordered, so a stream keeps reusing its buffer;
 //  * a launch on another stream takes a buffer whose last launch has completed, or a new one -- two
-//    launches that may overlap never share tickets / partial counts / granules;
+//    launches that may overlap never share tickets / partial counts / granules / filtered frames;
 //  * during stream capture nothing can be allocated, and the pointer is baked into the graph: the buffer
-//    must exist already (d2pc_reserve) and from then on belongs to that capture alone -- it is never
-//    freed, grown or handed to another launch, so replaying the graph stays valid whatever is called later.
-int acquire_state(d2pc_ctx *ctx, hipStream_t stream, size_t need, StateBuf *fixed, StateBuf **out) {
+//    must exist already (d2pc_reserve / d2pc_reserve_mono) and from then on belongs to that capture alone --
+//    it is never freed, grown or handed to another launch until d2pc_release_graph_buffers, so replaying the
+//    graph stays valid whatever is called later.  Launches of one capture share a buffer only when they are
+//    captured on the SAME stream (ordered inside the graph); a forked capture stream gets its own.
+int acquire_buf(d2pc_ctx *ctx, BufPool &pool, hipStream_t stream, size_t need, size_t need2, StateBuf *fixed,
+                StateBuf **out) {
   unsigned long long cid = 0;
   const bool capturing = capture_info(stream, &cid);
   if (fixed) {  // pipeline slot: the slot's stream orders everything that touches its buffer
     if (capturing) return fail(ctx, D2PC_ERR_INVALID_ARG, "pipeline streams cannot be captured");
-    int st = state_alloc(ctx, *fixed, need);
+    int st = state_alloc(ctx, nullptr, *fixed, need);
     if (st != D2PC_OK) return st;
     fixed->stream = stream;
     fixed->bound = true;
     *out = fixed;
     return D2PC_OK;
   }
+  auto fits = [&](const StateBuf *b) { return b->cap >= need && b->cap2 >= need2; };
   StateBuf *pick = nullptr;
   if (capturing) {
-    for (StateBuf &b : ctx->states)  // an earlier launch of the same capture: ordered inside the graph
-      if (b.p && b.captured && b.capture_id == cid && b.cap >= need) pick = &b;
+    for (StateBuf *b : pool.bufs)  // an earlier launch of the same capture on the same stream: ordered inside the graph
+      if (b->captured && b->capture_id == cid && b->bound && b->stream == stream && fits(b)) pick = b;
     if (!pick)
-      for (StateBuf &b : ctx->states)
-        if (b.p && !b.captured && b.cap >= need && state_idle(b) && (!pick || b.cap < pick->cap)) pick = &b;
+      for (StateBuf *b : pool.bufs)
+        if ((b->p || b->p2) && !b->captured && fits(b) && state_idle(*b) && (!pick || b->cap < pick->cap)) pick = b;
     if (!pick)
       return fail(ctx, D2PC_ERR_OUT_OF_MEMORY,
-                  "no free compaction state of %zu bytes for a captured launch: call d2pc_reserve(width, height, "
-                  "n_frames) for the largest batch before every capture", need);
+                  "no free %s of %zu bytes for a captured launch: reserve it (d2pc_reserve / d2pc_reserve_mono for the "
+                  "largest batch) before every capture", pool.what, need + need2);
     pick->captured = true;
     pick->capture_id = cid;
   } else {
-    for (StateBuf &b : ctx->states)
-      if (b.p && !b.captured && b.bound && b.stream == stream) pick = &b;
-    if (!pick)  // the smallest idle buffer that fits, else any idle one (it is grown), else an empty slot
-      for (StateBuf &b : ctx->states)
-        if (b.p && !b.captured && state_idle(b) && b.cap >= need && (!pick || b.cap < pick->cap)) pick = &b;
+    for (StateBuf *b : pool.bufs)
+      if (!b->captured && b->bound && b->stream == stream) pick = b;
+    if (!pick)  // the smallest idle buffer that fits, else any idle one (it is grown), else a new one
+      for (StateBuf *b : pool.bufs)
+        if (!b->captured && state_idle(*b) && fits(b) && (!pick || b->cap < pick->cap)) pick = b;
     if (!pick)
-      for (StateBuf &b : ctx->states)
-        if (b.p && !b.captured && state_idle(b)) pick = &b;
-    if (!pick)
-      for (StateBuf &b : ctx->states)
-        if (!b.p && !pick) pick = &b;
-    if (!pick) {  // every slot is busy on some other stream: wait for one that is not a graph's
-      for (StateBuf &b : ctx->states)
-        if (!b.captured && !pick) pick = &b;
-      if (!pick)
-        return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "all %d compaction state buffers belong to captured graphs", kMaxStateBufs);
+      for (StateBuf *b : pool.bufs)
+        if (!b->captured && state_idle(*b)) pick = b;
+    if (!pick && eager_bufs(pool) < kMaxEagerBufs) {
+      pick = new (std::nothrow) StateBuf();
+      if (!pick) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "out of host memory");
+      pool.bufs.push_back(pick);
     }
-    int st = state_alloc(ctx, *pick, need);  // waits for the buffer's last launch before it frees anything
+    if (!pick)  // every eager buffer is busy on some other stream: wait for one
+      for (StateBuf *b : pool.bufs)
+        if (!b->captured && !pick) pick = b;
+    int st = state_alloc(ctx, &pool, *pick, need, need2);  // waits for the buffer's last launch before it frees anything
     if (st != D2PC_OK) return st;
     if (pick->pending && !(pick->bound && pick->stream == stream)) {
-      // taken over from another stream while busy (only when all slots were busy): order behind it
+      // taken over from another stream while busy (only when all buffers were busy): order behind it
       D2PC_HIP(ctx, hipStreamWaitEvent(stream, pick->done, 0));
     }
   }
@@ -321,6 +360,36 @@ int acquire_state(d2pc_ctx *ctx, hipStream_t stream, size_t need, StateBuf *fixe
   pick->bound = true;
   *out = pick;
   return D2PC_OK;
+}
+
+// d2pc_reserve / d2pc_reserve_mono: ONE idle buffer of the pool that no graph owns, of at least this size
+int reserve_buf(d2pc_ctx *ctx, BufPool &pool, size_t need, size_t need2) {
+  if (need > pool.reserve) pool.reserve = need;
+  if (need2 > pool.reserve2) pool.reserve2 = need2;
+  StateBuf *pick = nullptr;
+  for (StateBuf *b : pool.bufs)
+    if (!b->captured && state_idle(*b) && b->cap >= need && b->cap2 >= need2) return D2PC_OK;
+  for (StateBuf *b : pool.bufs)  // an idle one that is too small is grown
+    if (!b->captured && state_idle(*b) && !pick) pick = b;
+  if (!pick && eager_bufs(pool) < kMaxEagerBufs) {
+    pick = new (std::nothrow) StateBuf();
+    if (!pick) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "out of host memory");
+    pool.bufs.push_back(pick);
+  }
+  if (!pick)
+    for (StateBuf *b : pool.bufs)
+      if (!b->captured && !pick) pick = b;  // all busy: state_alloc waits for this one
+  return state_alloc(ctx, &pool, *pick, need, need2);
+}
+
+void free_pool(BufPool &pool) {
+  for (StateBuf *b : pool.bufs) {
+    if (b->p) (void)hipFree(b->p);
+    if (b->p2) (void)hipFree(b->p2);
+    if (b->done) (void)hipEventDestroy(b->done);
+    delete b;
+  }
+  pool.bufs.clear();
 }
 
 int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d_out, uint32_t *d_idx,
@@ -386,8 +455,9 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     if (a.grid == 0) a.grid = 1;
   }
   a.state_bytes = compact_state_bytes(g);
+  a.stats = ctx->d_stats;
   StateBuf *sb = nullptr;
-  int st = acquire_state(ctx, stream, a.state_bytes, fixed_state, &sb);
+  int st = acquire_buf(ctx, ctx->states, stream, a.state_bytes, 0, fixed_state, &sb);
   if (st != D2PC_OK) return st;
   a.state = sb->p;
   sb->algo = a.compact_algo;
@@ -567,6 +637,8 @@ int d2pc_create(const d2pc_config *cfg, d2pc_ctx **out) {
   d2pc_ctx *ctx = new (std::nothrow) d2pc_ctx();
   if (!ctx) return D2PC_ERR_OUT_OF_MEMORY;
   ctx->cfg = *cfg;
+  ctx->states.what = "compaction state";
+  ctx->cb_scratch.what = "callback scratch";
   ctx->device = cfg->device_id;
   DeviceGuard guard(ctx->device);
   hipDeviceProp_t prop;
@@ -577,6 +649,8 @@ int d2pc_create(const d2pc_config *cfg, d2pc_ctx **out) {
   ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), 65536 * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), sizeof(CompactStats)) != hipSuccess ||
+      hipMemset(ctx->d_stats, 0, sizeof(CompactStats)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts), 65536 * sizeof(uint32_t), hipHostMallocDefault) !=
           hipSuccess) {
     d2pc_destroy(ctx);
@@ -590,16 +664,15 @@ int d2pc_destroy(d2pc_ctx *ctx) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (StateBuf &b : ctx->states) {
-    if (b.p) (void)hipFree(b.p);
-    if (b.done) (void)hipEventDestroy(b.done);
-  }
+  free_pool(ctx->states);
+  free_pool(ctx->cb_scratch);
   if (ctx->d_in) (void)hipFree(ctx->d_in);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_idx) (void)hipFree(ctx->d_idx);
   if (ctx->d_med) (void)hipFree(ctx->d_med);
   if (ctx->d_cvt) (void)hipFree(ctx->d_cvt);
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+  if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
   for (PipeSlot &sl : ctx->slots) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
@@ -622,8 +695,7 @@ int d2pc_destroy(d2pc_ctx *ctx) {
   for (hipEvent_t e : ctx->cb_events) (void)hipEventDestroy(e);
   if (ctx->cb_stream_m) (void)hipStreamDestroy(ctx->cb_stream_m);
   if (ctx->cb_stream_r) (void)hipStreamDestroy(ctx->cb_stream_r);
-  if (ctx->d_cb_med) (void)hipFree(ctx->d_cb_med);
-  if (ctx->d_cb_cvt) (void)hipFree(ctx->d_cb_cvt);
+  if (ctx->cb_overlap_done) (void)hipEventDestroy(ctx->cb_overlap_done);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return D2PC_OK;
@@ -760,6 +832,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "host_direct_read") && (value == 0 || value == 1)) ctx->host_direct_read = value;
   else if (!strcmp(key, "median_algo") && value >= 0 && value <= 2) ctx->median_algo = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
+  else if (!strcmp(key, "membench_blocks_per_cu") && value >= 1 && value <= 256) ctx->membench_blocks_per_cu = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
   return D2PC_OK;
 }
@@ -773,18 +846,45 @@ int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames) {
   if (st != D2PC_OK) return st;
   // Guarantees ONE free (idle, not owned by a captured graph) buffer of this size, and makes it the
   // minimum size of every buffer allocated later.  Call it before each capture that contains a COMPACT launch.
-  const size_t need = compact_state_bytes(g);
-  if (need > ctx->state_reserve) ctx->state_reserve = need;
-  StateBuf *pick = nullptr;
-  for (StateBuf &b : ctx->states)
-    if (b.p && !b.captured && state_idle(b) && b.cap >= need) return D2PC_OK;
-  for (StateBuf &b : ctx->states)
-    if (!b.p && !pick) pick = &b;
-  if (!pick)
-    for (StateBuf &b : ctx->states)
-      if (!b.captured && !pick) pick = &b;
-  if (!pick) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "all %d compaction state buffers belong to captured graphs", kMaxStateBufs);
-  return state_alloc(ctx, *pick, need);
+  return reserve_buf(ctx, ctx->states, compact_state_bytes(g), 0);
+}
+
+int d2pc_reserve_mono(d2pc_ctx *ctx, int dtype, int width, int height, int n_frames) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (dtype != D2PC_DTYPE_U8 && dtype != D2PC_DTYPE_MONO16) return fail(ctx, D2PC_ERR_BAD_DTYPE, "dtype %d is not U8 / MONO16", dtype);
+  if (width <= 0 || height <= 0 || n_frames <= 0 || n_frames > 65535)
+    return fail(ctx, D2PC_ERR_BAD_SIZE, "bad size %dx%d x%d", width, height, n_frames);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  const size_t bytes = ((size_t(width) + 255) & ~size_t(255)) * size_t(height) * size_t(n_frames);
+  int st = reserve_buf(ctx, ctx->cb_scratch, bytes, dtype == D2PC_DTYPE_MONO16 ? bytes : 0);
+  if (st != D2PC_OK) return st;
+  return ctx->cfg.mode == D2PC_MODE_COMPACT ? d2pc_reserve(ctx, width, height, n_frames) : D2PC_OK;
+}
+
+int d2pc_release_graph_buffers(d2pc_ctx *ctx) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  for (BufPool *pool : {&ctx->states, &ctx->cb_scratch}) {
+    for (StateBuf *b : pool->bufs)
+      if (b->captured) {
+        b->captured = false;
+        b->bound = false;
+        b->pending = false;  // the caller has destroyed the graphs: nothing of theirs is in flight
+        b->algo = 0;
+      }
+    // back under the cap on eager buffers: the surplus (idle by the above) is freed
+    for (size_t i = pool->bufs.size(); i-- > 0 && eager_bufs(*pool) > kMaxEagerBufs;) {
+      StateBuf *b = pool->bufs[i];
+      if (b->captured || !state_idle(*b)) continue;
+      if (b->p) (void)hipFree(b->p);
+      if (b->p2) (void)hipFree(b->p2);
+      if (b->done) (void)hipEventDestroy(b->done);
+      delete b;
+      pool->bufs.erase(pool->bufs.begin() + long(i));
+    }
+  }
+  return D2PC_OK;
 }
 
 int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scale, int width, int height,
@@ -826,25 +926,118 @@ int d2pc_check_async_error(d2pc_ctx *ctx) {
   DeviceGuard guard(ctx->device);
   // every buffer remembers the algorithm of ITS last launch: a small two-pass launch after a big single-pass
   // one (another buffer, or the same one re-used) neither hides the big launch's flag nor inherits a stale one
-  for (const StateBuf &b : ctx->states) {
+  for (const StateBuf *b : ctx->states.bufs) {
     bool bad = false;
-    int st = state_timed_out(ctx, b, &bad);
+    int st = state_timed_out(ctx, *b, &bad);
     if (st != D2PC_OK) return st;
     if (bad) return fail(ctx, D2PC_ERR_INTERNAL, "compaction hand-off spin expired");
   }
   return D2PC_OK;
 }
 
+// Single-pass counters: what the launches' blocks left in the state headers (folded into ctx->d_stats by the NEXT
+// launch's k_state_clear) plus the headers not folded yet.  The caller has synchronised its streams.
+int d2pc_compact_stats(d2pc_ctx *ctx, d2pc_compact_stats_t *out) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!out || out->struct_size != sizeof(d2pc_compact_stats_t)) return fail(ctx, D2PC_ERR_INVALID_ARG, "bad d2pc_compact_stats_t");
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  CompactStats acc;
+  D2PC_HIP(ctx, hipMemcpy(&acc, ctx->d_stats, sizeof acc, hipMemcpyDeviceToHost));
+  acc.launches += ctx->stats_host.launches;
+  acc.tiles += ctx->stats_host.tiles;
+  acc.failed_polls += ctx->stats_host.failed_polls;
+  acc.wait_ticks += ctx->stats_host.wait_ticks;
+  acc.timeouts += ctx->stats_host.timeouts;
+  auto add_header = [&](const StateBuf &b) -> int {
+    if (!b.p || b.cap < sizeof(StateHeader)) return D2PC_OK;
+    StateHeader h;
+    D2PC_HIP(ctx, hipMemcpy(&h, b.p, sizeof h, hipMemcpyDeviceToHost));
+    if (!h.launches) return D2PC_OK;  // never used by the single pass, or folded and not relaunched
+    acc.launches += h.launches;
+    acc.tiles += h.tiles;
+    acc.failed_polls += h.failed_polls;
+    acc.wait_ticks += h.wait_ticks;
+    acc.timeouts += h.timeout ? 1 : 0;
+    return D2PC_OK;
+  };
+  for (const StateBuf *b : ctx->states.bufs) {
+    int st = add_header(*b);
+    if (st != D2PC_OK) return st;
+  }
+  for (int i = 0; i < ctx->pipe_depth; ++i) {
+    int st = add_header(ctx->slots[i].st);
+    if (st != D2PC_OK) return st;
+  }
+  out->launches = acc.launches;
+  out->tiles = acc.tiles;
+  out->failed_polls = acc.failed_polls;
+  out->wait_us = acc.wait_ticks / (kSpinTicksPerMs / 1000u);
+  out->timeouts = acc.timeouts;
+  out->twopass_fallbacks = ctx->n_twopass_fallbacks;
+  return D2PC_OK;
+}
+
+int d2pc_compact_stats_reset(d2pc_ctx *ctx) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  D2PC_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(CompactStats)));
+  // the counters of each buffer's last launch (the timeout flag stays: d2pc_check_async_error reads it)
+  auto clear_header = [&](const StateBuf &b) -> int {
+    if (!b.p || b.cap < sizeof(StateHeader)) return D2PC_OK;
+    D2PC_HIP(ctx, hipMemset(static_cast<char *>(b.p) + offsetof(StateHeader, launches), 0,
+                            offsetof(StateHeader, diag) - offsetof(StateHeader, launches)));
+    return D2PC_OK;
+  };
+  for (const StateBuf *b : ctx->states.bufs) {
+    int st = clear_header(*b);
+    if (st != D2PC_OK) return st;
+  }
+  for (int i = 0; i < ctx->pipe_depth; ++i) {
+    int st = clear_header(ctx->slots[i].st);
+    if (st != D2PC_OK) return st;
+  }
+  ctx->n_twopass_fallbacks = 0;
+  ctx->stats_host = CompactStats{};
+  return D2PC_OK;
+}
+
+int d2pc_membench_fill(d2pc_ctx *ctx, void *d_dst, size_t bytes, void *stream) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!d_dst || bytes < 16 || bytes % 16 != 0 || reinterpret_cast<uintptr_t>(d_dst) % 16 != 0)
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "fill needs a 16-byte aligned buffer of a multiple of 16 bytes");
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  D2PC_HIP(ctx, launch_membench_fill(d_dst, bytes, uint32_t(ctx->cu_count * ctx->membench_blocks_per_cu),
+                                     static_cast<hipStream_t>(stream)));
+  return D2PC_OK;
+}
+
+int d2pc_membench_copy(d2pc_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, void *stream) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (!d_src || !d_dst || bytes < 16 || bytes % 16 != 0 || reinterpret_cast<uintptr_t>(d_dst) % 16 != 0 ||
+      reinterpret_cast<uintptr_t>(d_src) % 16 != 0)
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "copy needs 16-byte aligned buffers of a multiple of 16 bytes");
+  const uintptr_t s0 = reinterpret_cast<uintptr_t>(d_src), d0 = reinterpret_cast<uintptr_t>(d_dst);
+  if (s0 < d0 + bytes && d0 < s0 + bytes) return fail(ctx, D2PC_ERR_INVALID_ARG, "source and destination overlap");
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
+  D2PC_HIP(ctx, launch_membench_copy(d_src, d_dst, bytes, uint32_t(ctx->cu_count * ctx->membench_blocks_per_cu),
+                                     static_cast<hipStream_t>(stream)));
+  return D2PC_OK;
+}
+
 #ifdef D2PC_DIAG
-// diagnostic build only: copy the 64-byte state header (phase timers) out
+// diagnostic build only: copy the 128-byte state header (phase timers) out
 int d2pc_debug_read_header(d2pc_ctx *ctx, void *out64) {
   const StateBuf *last = nullptr;  // diagnostic runs use one stream: the buffer of the last single-pass launch
   if (ctx)
-    for (const StateBuf &b : ctx->states)
-      if (b.p && b.algo == 2) last = &b;
+    for (const StateBuf *b : ctx->states.bufs)
+      if (b->p && b->algo == 2) last = b;
   if (!last) return D2PC_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
-  D2PC_HIP(ctx, hipMemcpy(out64, last->p, 64, hipMemcpyDeviceToHost));
+  D2PC_HIP(ctx, hipMemcpy(out64, last->p, sizeof(StateHeader), hipMemcpyDeviceToHost));
   return D2PC_OK;
 }
 #endif
@@ -954,7 +1147,9 @@ static int process_host_frame(d2pc_ctx *ctx, const void *disp, int dtype, float 
     D2PC_HIP(ctx, hipStreamSynchronize(s));
     if (ctx->h_counts[0] == kCountTimedOut) {
       // the single pass gave up waiting for a predecessor (only ever selected here by cfg.compact_algo = 2):
-      // this entry point is synchronous, so run the frame again with the two-pass form, which cannot wait
+      // this entry point is synchronous, so run the frame again with the two-pass form, which cannot wait.
+      // Counted: d2pc_compact_stats reports these reruns (twopass_fallbacks) and the launch that timed out.
+      ++ctx->n_twopass_fallbacks;
       st = enqueue(ctx, g, kernel_in, kdtype, kout, kidx, ctx->d_counts, s, nullptr, 1);
       if (st != D2PC_OK) return st;
       D2PC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1107,6 +1302,13 @@ int callback_event(d2pc_ctx *ctx, size_t i, hipEvent_t *e) {
   return D2PC_OK;
 }
 
+// Can the tile-fused kernel (median + points per tile) serve this call?
+bool callback_one_kernel_ok(const d2pc_ctx *ctx, bool compact, const Geom &g) {
+  (void)ctx;
+  (void)g;
+  return !compact;
+}
+
 }  // namespace
 
 extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int dtype, int width, int height,
@@ -1140,26 +1342,30 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
   const bool capturing = capture_info(user, nullptr);
   // scratch: the 8-bit frames on a 256-byte pitch
   const size_t kpitch = (size_t(width) + 255) & ~size_t(255), kframe = kpitch * size_t(height);
-  if (bridge16 && kframe * size_t(n_frames) > ctx->cb_cvt_cap) {
-    if (capturing) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "scratch not allocated yet: run this batch size once before capturing");
-    if ((st = grow(ctx, &ctx->d_cb_cvt, &ctx->cb_cvt_cap, kframe * size_t(n_frames))) != D2PC_OK) return st;
-  }
   // (the same decisions as below: chunked overlap?  filter + points in one kernel, which needs no filtered frames?)
   const int want_chunks = ctx->cb_chunks > n_frames ? n_frames : ctx->cb_chunks;
   const bool will_overlap = want_chunks > 1 && !capturing && (median || bridge16) &&
                             uint64_t(width) * uint64_t(height) * uint64_t(n_frames) / uint64_t(want_chunks) >= (uint64_t(16) << 20);
   bool one_kernel = false;
-  if (median && ctx->cb_fused == 1 && !compact && !will_overlap) {
+  if (median && ctx->cb_fused == 1 && !will_overlap) {
     MedianArgs probe;
     probe.algo = ctx->median_algo;
     probe.n_frames = uint32_t(n_frames);
     median_roi_only(probe, gin, height);
-    one_kernel = median_uses_bs(probe, median_ksize);
+    one_kernel = median_uses_bs(probe, median_ksize) && callback_one_kernel_ok(ctx, compact, gin);
   }
-  if (median && !one_kernel && kframe * size_t(n_frames) > ctx->cb_med_cap) {
-    if (capturing) return fail(ctx, D2PC_ERR_OUT_OF_MEMORY, "scratch not allocated yet: run this batch size once before capturing");
-    if ((st = grow(ctx, &ctx->d_cb_med, &ctx->cb_med_cap, kframe * size_t(n_frames))) != D2PC_OK) return st;
+  // The filtered (and rescaled) frames of the two-launch form live in a scratch buffer that belongs to THIS stream's
+  // work: like the compaction state, one per stream in flight, so that double-buffered use of a context on two
+  // streams never overwrites another call's filtered frames (advisor, round 2).  A capture takes an existing idle
+  // one (d2pc_reserve_mono, or a call of this size made earlier) and keeps it.
+  const size_t need_med = median && !one_kernel ? kframe * size_t(n_frames) : 0;
+  const size_t need_cvt = bridge16 ? kframe * size_t(n_frames) : 0;
+  StateBuf *scratch = nullptr;
+  if (need_med || need_cvt) {
+    if ((st = acquire_buf(ctx, ctx->cb_scratch, user, need_med, need_cvt, nullptr, &scratch)) != D2PC_OK) return st;
   }
+  void *const d_cb_med = scratch ? scratch->p : nullptr;
+  void *const d_cb_cvt = scratch ? scratch->p2 : nullptr;
   // Few, large chunks: a cross-stream dependency costs ~20 us on this runtime (measured: 16 one-frame chunks of
   // 4K frames are 19 % SLOWER than running in order, 2 chunks 8 % faster), so the batch is only cut when every
   // chunk carries well over that in kernel time
@@ -1171,6 +1377,10 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
   hipStream_t sm = user, sr = user;
   if (overlap) {
     if ((st = callback_streams(ctx)) != D2PC_OK) return st;
+    // the two internal streams and their events are ONE set per context: a second overlapped call (from any
+    // stream) is ordered behind the previous one
+    if (!ctx->cb_overlap_done) D2PC_HIP(ctx, hipEventCreateWithFlags(&ctx->cb_overlap_done, hipEventDisableTiming));
+    if (ctx->cb_overlap_pending) D2PC_HIP(ctx, hipStreamWaitEvent(user, ctx->cb_overlap_done, 0));
     sm = ctx->cb_stream_m;
     sr = ctx->cb_stream_r;
     hipEvent_t fork;
@@ -1195,7 +1405,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
       m.dst_row_stride = uint32_t(kpitch);
       m.src_frame_stride = frame_stride;
       m.dst_frame_stride = kframe;
-      uint8_t *dst = static_cast<uint8_t *>(ctx->d_cb_cvt) + size_t(f0) * kframe;
+      uint8_t *dst = static_cast<uint8_t *>(d_cb_cvt) + size_t(f0) * kframe;
       D2PC_HIP(ctx, launch_mono16_to_mono8(src, dst, m, sm));
       kin = dst;
       kin_pitch = kpitch;
@@ -1207,7 +1417,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
       m.src_frame_stride = kin_frame;
       m.dst_frame_stride = kframe;
       median_roi_only(m, gin, height);
-      if (ctx->cb_fused == 1 && !compact && !overlap && median_uses_bs(m, median_ksize)) {
+      if (one_kernel) {
         // filter and points tile by tile in one kernel; the filtered frames never reach memory
         Geom g;
         if ((st = make_geom(ctx, D2PC_DTYPE_U8, scale, width, height, kin_pitch, kin_frame, nf, out_frame_stride, pxt, &g)) != D2PC_OK)
@@ -1225,7 +1435,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
         D2PC_HIP(ctx, launch_callback_bs(a, m, kin, median_ksize));
         continue;
       }
-      uint8_t *dst = static_cast<uint8_t *>(ctx->d_cb_med) + size_t(f0) * kframe;
+      uint8_t *dst = static_cast<uint8_t *>(d_cb_med) + size_t(f0) * kframe;
       D2PC_HIP(ctx, launch_median(kin, dst, m, median_ksize, sm));
       kin = dst;
       kin_pitch = kpitch;
@@ -1249,6 +1459,12 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
     if ((st = callback_event(ctx, ev++, &join)) != D2PC_OK) return st;
     D2PC_HIP(ctx, hipEventRecord(join, sr));  // every filter launch is ordered before a reprojection on sr
     D2PC_HIP(ctx, hipStreamWaitEvent(user, join, 0));
+    D2PC_HIP(ctx, hipEventRecord(ctx->cb_overlap_done, user));
+    ctx->cb_overlap_pending = true;
+  }
+  if (scratch && !scratch->captured) {  // (inside a capture the record would become a graph node; the buffer is the graph's)
+    D2PC_HIP(ctx, hipEventRecord(scratch->done, user));
+    scratch->pending = true;
   }
   return D2PC_OK;
 }

@@ -78,7 +78,7 @@ enum : int { DT_F32 = 0, DT_U8 = 1, DT_U16 = 2 };
 enum : int { QK_GENERAL = 0, QK_STEREO = 1 };
 
 // ---- compaction state (zeroed by a memset node before every launch) -------
-//   [StateHeader 64 B][frame 0 state][frame 1 state]...
+//   [StateHeader 128 B][frame 0 state][frame 1 state]...
 //   frame state (frame_state_stride bytes, 256-B aligned):
 //     [ticket u32 alone in 256 B][group_acc u64, one per 128-B line][16 B x tiles]
 //   the 16 B per tile hold one u64 granule (single pass) or 4 x u32 wave counts (two-pass)
@@ -87,8 +87,20 @@ enum : int { QK_GENERAL = 0, QK_STEREO = 1 };
 struct StateHeader {
   uint32_t timeout;       // set to 1 if a bounded spin expired
   uint32_t pad;
+  // production counters of the single pass, summed over the launch's blocks at their exit (one atomic each per
+  // block); k_state_clear folds them into the context's CompactStats before it zeroes the header for the next launch
+  unsigned long long launches;      // 1 (written by k_state_clear)
+  unsigned long long tiles;         // tiles served
+  unsigned long long failed_polls;  // polls of a predecessor's count that found it not yet published
+  unsigned long long wait_ticks;    // time control waves spent in such waits, 100 MHz ticks, summed over blocks
   // diagnostic build only (-DD2PC_DIAG): shader-clock sums over all tiles
-  unsigned long long diag[7];  // tiles, spins, t_compute, t_ticket, t_wait, t_scatter, t_total
+  unsigned long long diag[7];  // iterations, spins, t_compute, t_ticket, t_wait, t_scatter, t_total
+  unsigned long long pad2[4];
+};
+static_assert(sizeof(StateHeader) == 128, "the header is one 128-byte line");
+// Accumulated over a context's single-pass launches (device memory, never cleared by a launch).
+struct CompactStats {
+  unsigned long long launches, tiles, failed_polls, wait_ticks, timeouts, pad[3];
 };
 constexpr uint32_t kFrameTicketBytes = 256;   // the ticket word has a 256-B block to itself
 constexpr uint32_t kGroupAccStride = 128;     // one group accumulator per 128-B line

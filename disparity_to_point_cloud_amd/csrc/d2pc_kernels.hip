@@ -19,6 +19,9 @@
 //    (slot, wave) counts, and a two-level counted prefix across tiles
 //    (64-bit {arrivals,sum} group accumulators + tagged per-tile granules)
 //    so the output order equals the CPU loop's row-major order bit-for-bit.
+#include <cstdio>
+#include <cstdlib>
+
 #include "d2pc_device.hpp"
 #include "d2pc_launch.hpp"
 #include "d2pc_median_bs_tile.hpp"
@@ -50,6 +53,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #endif
 #ifndef D2PC_SCATTER_STORE_NT
 #define D2PC_SCATTER_STORE_NT 1
+#endif
+#ifndef D2PC_CLEAR_WITH_MEMSET
+#define D2PC_CLEAR_WITH_MEMSET 0
 #endif
 template <class T>
 __device__ __forceinline__ T ld(const T *p) {
@@ -499,6 +505,12 @@ __device__ __forceinline__ void backoff(uint32_t spins) {
   for (uint32_t j = 0; j < n; ++j) __builtin_amdgcn_s_sleep(1);
 }
 
+// What a control wave's waits cost, summed over the block's tiles (wave-uniform).
+struct PollStats {
+  uint32_t failed = 0;  // polls that found the word not ready
+  uint32_t ticks = 0;   // 100 MHz ticks spent in waits that needed more than the first look
+};
+
 // Waits (WAIT) until the 64-bit word at p satisfies `ready`, and returns it.
 // First look is a normal cached load: a word that already carries its
 // completion mark (all 64 arrivals / the granule tag) is final, so a cached
@@ -506,7 +518,7 @@ __device__ __forceinline__ void backoff(uint32_t spins) {
 // with agent-scope (coherent) loads, with back-off.
 template <bool WAIT, class Ready>
 __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, StateHeader *hdr, uint32_t lane,
-                                                 uint32_t &spin_acc, uint32_t spin_ticks, Ready ready) {
+                                                 PollStats &ps, uint32_t spin_ticks, Ready ready) {
   using gu64 = __attribute__((address_space(1))) const uint64_t;
   uint64_t v = 0;
   if constexpr (!WAIT) {
@@ -534,7 +546,10 @@ __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, Sta
         break;
       }
     }
-    spin_acc += spins;  // read by the diagnostic build only
+    if (spins) {  // production counters (d2pc_compact_stats): failed polls and the time they took
+      ps.failed += spins;
+      ps.ticks += uint32_t(__builtin_amdgcn_s_memrealtime() - t0);
+    }
     return v;
   }
 }
@@ -552,14 +567,14 @@ struct KnownGroups {
 
 template <bool WAIT>
 __device__ __forceinline__ uint32_t prefix_before(const FrameState &fs, StateHeader *hdr, uint32_t lt,
-                                                  uint32_t lane, uint32_t &spin_acc, KnownGroups &known,
+                                                  uint32_t lane, PollStats &ps, KnownGroups &known,
                                                   uint32_t spin_ticks) {
   const uint32_t grp = lt / kGroupTiles;
   uint32_t sum = 0;
   for (uint32_t g0 = known.groups; g0 < grp; g0 += 64) {  // groups below grp hold kGroupTiles tiles each
     const uint32_t gi = g0 + lane;
     const bool on = gi < grp;
-    const uint64_t v = read_counted<WAIT>(fs.group_word(gi), on, hdr, lane, spin_acc, spin_ticks,
+    const uint64_t v = read_counted<WAIT>(fs.group_word(gi), on, hdr, lane, ps, spin_ticks,
                                           [](uint64_t x) { return uint32_t(x >> 32) == uint32_t(kGroupTiles); });
     sum += on ? uint32_t(v) : 0u;
   }
@@ -571,7 +586,7 @@ __device__ __forceinline__ uint32_t prefix_before(const FrameState &fs, StateHea
   {  // tiles grp*64 .. lt-1 of the own group (< 64 of them)
     const uint32_t ti = grp * kGroupTiles + lane;
     const bool on = ti < lt;
-    const uint64_t v = read_counted<WAIT>(fs.granules + 2u * ti, on, hdr, lane, spin_acc, spin_ticks,
+    const uint64_t v = read_counted<WAIT>(fs.granules + 2u * ti, on, hdr, lane, ps, spin_ticks,
                                           [](uint64_t x) { return (x & kGranuleTag) != 0; });
     sum += on ? uint32_t(v) : 0u;
   }
@@ -993,7 +1008,8 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
   __shared__ float s_tile[4 * kStage];
   float *const my_tile = s_tile + (wave < kBlock / 64 ? wave : 0u) * kWaveStage;
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
-  uint32_t spin_acc = 0;
+  PollStats polls;
+  uint32_t served = 0;  // control wave: tiles this block took
 #ifdef D2PC_DIAG
   // phase timers (shader clock), lane 0 of worker wave 0 and of the control wave; named
   // scalars on purpose: a runtime-indexed array would live in scratch and distort the run
@@ -1041,10 +1057,11 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
         uint32_t tk = 0;
         if (cur != kNoTile && lane == 0) tk = atomicAdd(fs.ticket, 1u);
         if (prev2 != kNoTile) {
-          const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, spin_acc, known, g.spin_ticks);
+          const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, polls, known, g.spin_ticks);
           if (lane == 0) s_prefix[slot] = p;
         }
         if (cur != kNoTile && lane == 0) s_next[slot] = tk;
+        served += cur != kNoTile ? 1u : 0u;
       } else if (cur != kNoTile) {
         float dc[PXT];
         stage_read<PXT>(dc, my_tile + (it & 3u) * kStage, lane);
@@ -1127,6 +1144,13 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
     // prefix it never obtained), whether or not the frame's last tile has reported its count already
     if (counts && tid == 0 && __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       __hip_atomic_store(counts + f, kCountTimedOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ctl && lane == 0) {  // the block's share of the launch's counters (no-return atomics, once per block)
+      atomicAdd(&hdr->tiles, (unsigned long long)served);
+      if (polls.failed) {
+        atomicAdd(&hdr->failed_polls, (unsigned long long)polls.failed);
+        atomicAdd(&hdr->wait_ticks, (unsigned long long)polls.ticks);
+      }
+    }
   }
 #ifdef D2PC_DIAG
   if (lane == 0 && wave == 0) {
@@ -1137,7 +1161,7 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
     atomicAdd(&hdr->diag[5], tD);
   }
   if (lane == 0 && ctl) {
-    atomicAdd(&hdr->diag[1], (unsigned long long)spin_acc);
+    atomicAdd(&hdr->diag[1], (unsigned long long)polls.failed);
     atomicAdd(&hdr->diag[6], tA);  // control: ticket + prefix
   }
 #endif
@@ -1171,13 +1195,29 @@ static hipError_t launch_parity_t(const LaunchArgs &a) {
 }
 
 // Zeroes the compaction state ahead of a single-pass launch.  A kernel of our own rather than
-// hipMemsetAsync: inside a captured graph the runtime's memset node did not reliably leave zeroed state
-// for the kernel node behind it on replays (stale tickets and a stale timeout flag on the second replay,
-// MI355X / ROCm 7.2), and a plain kernel node has exactly the ordering and cache behaviour of the
-// kernels around it.
-__global__ __launch_bounds__(256) void k_state_clear(uint4 *__restrict__ p, uint32_t n16) {
+// hipMemsetAsync: see tools/graph_memset_repro.hip and DESIGN.md section 7 for what was observed with a
+// memset node in a captured graph; a plain kernel node has exactly the ordering and cache behaviour of the
+// kernels around it.  Thread 0 first folds the PREVIOUS launch's counters (left in the header by its blocks)
+// into the context's accumulators, then starts the new header with launches = 1.
+__global__ __launch_bounds__(256) void k_state_clear(uint4 *__restrict__ p, uint32_t n16, CompactStats *stats) {
+  constexpr uint32_t kHdr16 = uint32_t(sizeof(StateHeader) / 16);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i < n16) p[i] = uint4{0u, 0u, 0u, 0u};
+  if (i == 0) {
+    StateHeader *h = reinterpret_cast<StateHeader *>(p);
+    const StateHeader old = *h;
+    if (old.launches) {
+      atomicAdd(&stats->launches, old.launches);
+      atomicAdd(&stats->tiles, old.tiles);
+      atomicAdd(&stats->failed_polls, old.failed_polls);
+      atomicAdd(&stats->wait_ticks, old.wait_ticks);
+      if (old.timeout) atomicAdd(&stats->timeouts, 1ull);
+    }
+    StateHeader fresh{};
+    fresh.launches = 1;
+    *h = fresh;
+  } else if (i >= kHdr16 && i < n16) {
+    p[i] = uint4{0u, 0u, 0u, 0u};
+  }
 }
 
 template <int DT, int QK, int PXT, bool VEC>
@@ -1195,7 +1235,13 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
                        a.out_index, a.counts, state, a.geom, make_qarg<QK>(a), selfscan);
   } else {
     const uint32_t n16 = uint32_t((a.state_bytes + 15) / 16);  // buffers are allocated in whole MiB
-    hipLaunchKernelGGL(k_state_clear, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(a.state), n16);
+#if D2PC_CLEAR_WITH_MEMSET  // experiment only (tools/graph_memset_probe.py): round 1's hipMemsetAsync instead of the kernel
+    if (getenv("D2PC_TRACE_MEMSET")) fprintf(stderr, "d2pc: hipMemsetAsync(%p, 0, %zu) on stream %p\n", a.state, a.state_bytes, (void *)a.stream);
+    if (hipError_t e = hipMemsetAsync(a.state, 0, a.state_bytes, a.stream); e != hipSuccess) return e;
+#else
+    hipLaunchKernelGGL(k_state_clear, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(a.state), n16,
+                       static_cast<CompactStats *>(a.stats));
+#endif
     // frame-static assignment: a block serves frame blockIdx % n_frames, so the grid is a multiple of
     // n_frames (the C ABI falls back to the two-pass form when there are more frames than blocks)
     uint32_t grid = a.grid;

@@ -17,6 +17,7 @@ struct LaunchArgs {
   uint32_t *counts = nullptr;     // device, nullable (required in COMPACT)
   void *state = nullptr;          // device: compaction state (COMPACT)
   size_t state_bytes = 0;
+  void *stats = nullptr;          // device: CompactStats of the context (single pass)
   int dtype = DT_F32;
   int pxt = 4;                    // ROI pixels per thread (tile = 256*pxt)
   int compact_algo = 1;           // 1 two-pass, 2 single-pass
@@ -94,5 +95,10 @@ hipError_t launch_parity(const LaunchArgs &a);
 // a.out_index (nullable), a.counts (nullable), a.q*, a.stream as in launch_parity
 hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src, int ksize);
 hipError_t launch_compact(const LaunchArgs &a);
+
+// Device calibration for bench.py (d2pc_membench.hip): a plain dwordx4 fill and a dwordx4 copy, the two
+// streaming shapes the roofline fraction of the reprojection kernel is read against on the SAME device
+hipError_t launch_membench_fill(void *dst, size_t bytes, uint32_t blocks, hipStream_t stream);
+hipError_t launch_membench_copy(const void *src, void *dst, size_t bytes, uint32_t blocks, hipStream_t stream);
 
 }  // namespace d2pc

@@ -50,6 +50,12 @@ class Disparity2PCloudT {
   double base_line_ = 0.09;  // Omni-stereo
   double Q_[16];             // hpp:72 (row-major 4x4)
   d2pc_ctx *ctx_ = nullptr;
+  // DisparityImageCb's own calibration and context: Q and min_disparity come from each MESSAGE there, and
+  // must never leak into DisparityCb's stereoRectify Q_ (hpp:104) when both topics are live
+  double Q_di_[16];
+  bool have_q_di_ = false;
+  d2pc_ctx *ctx_di_ = nullptr;
+  int device_id_ = 0, mode_ = D2PC_MODE_PARITY;
   Publisher p_cloud_pub_;
   bool verbose_ = false;
   bool gpu_median_ = true;  // cpp:55-57 on the device (d2pc_process_mono8) or on the host (Msgs::prepare)
@@ -62,7 +68,7 @@ class Disparity2PCloudT {
   // defaults cx' = 376 exactly; see include/d2pc.h for the other conventions).
   Disparity2PCloudT(const ParamSource &nh, Publisher pub, int device_id = 0, const double *q_from_opencv = nullptr,
                     int mode = D2PC_MODE_PARITY, bool verbose = false, bool gpu_median = true)
-      : p_cloud_pub_(std::move(pub)), verbose_(verbose), gpu_median_(gpu_median) {
+      : device_id_(device_id), mode_(mode), p_cloud_pub_(std::move(pub)), verbose_(verbose), gpu_median_(gpu_median) {
     if (verbose_) printf("Constructor start\n");
     nh.param("fx_", fx_, 714.24);
     nh.param("fy_", fy_, 713.5);
@@ -87,6 +93,7 @@ class Disparity2PCloudT {
     if (verbose_) d2pc_set_tuning(ctx_, "stage_timing", 1);  // the breadcrumbs below also say how long each stage took
   }
   ~Disparity2PCloudT() {
+    if (ctx_di_) d2pc_destroy(ctx_di_);
     if (ctx_) d2pc_destroy(ctx_);
   }
   Disparity2PCloudT(const Disparity2PCloudT &) = delete;
@@ -152,28 +159,37 @@ class Disparity2PCloudT {
     double q[16];
     if (d2pc_make_q_disparity_image(double(msg->f), double(msg->T), cx_, cy_, q) != D2PC_OK)
       throw std::runtime_error("DisparityImage: f and T must be positive");
-    bool same = true;
-    for (int i = 0; i < 16; ++i) same = same && q[i] == Q_[i];
-    if (!same) {  // recalibration: cameras rarely change f or T between frames
-      for (int i = 0; i < 16; ++i) Q_[i] = q[i];
-      check(d2pc_set_q(ctx_, Q_), "d2pc_set_q");
+    if (!ctx_di_) {  // first DisparityImage: a second context on the same device, same output mode
+      d2pc_config cfg;
+      d2pc_config_init(&cfg);
+      cfg.device_id = device_id_;
+      cfg.mode = mode_;
+      const int st = d2pc_create(&cfg, &ctx_di_);
+      if (st != D2PC_OK) throw std::runtime_error(std::string("d2pc_create (DisparityImage): ") + d2pc_status_string(st));
     }
-    check(d2pc_set_min_disparity(ctx_, msg->min_disparity), "d2pc_set_min_disparity");
+    bool same = have_q_di_;
+    for (int i = 0; i < 16 && same; ++i) same = q[i] == Q_di_[i];
+    if (!same) {  // recalibration: cameras rarely change f or T between frames
+      for (int i = 0; i < 16; ++i) Q_di_[i] = q[i];
+      check_di(d2pc_set_q(ctx_di_, Q_di_), "d2pc_set_q");
+      have_q_di_ = true;
+    }
+    check_di(d2pc_set_min_disparity(ctx_di_, msg->min_disparity), "d2pc_set_min_disparity");
     PointCloud2 output;
     const size_t cap = d2pc_roi_points(int(im.width), int(im.height), 40);
     output.data.resize(cap * 16);
     size_t n = 0;
-    check(d2pc_process(ctx_, im.data.data(), D2PC_DTYPE_F32, 1.0f, int(im.width), int(im.height), size_t(im.step),
-                       output.data.data(), nullptr, cap, &n),
-          "d2pc_process");
+    check_di(d2pc_process(ctx_di_, im.data.data(), D2PC_DTYPE_F32, 1.0f, int(im.width), int(im.height), size_t(im.step),
+                          output.data.data(), nullptr, cap, &n),
+             "d2pc_process");
     output.data.resize(n * 16);
     finish_and_publish(output, n, msg->header.stamp);
   }
 
  private:
-  void check(int st, const char *what) {
+  void check_di(int st, const char *what) {
     if (st != D2PC_OK)
-      throw std::runtime_error(std::string(what) + ": " + d2pc_status_string(st) + ": " + d2pc_last_error(ctx_));
+      throw std::runtime_error(std::string(what) + ": " + d2pc_status_string(st) + ": " + d2pc_last_error(ctx_di_));
   }
 
   // cpp:79-90

@@ -7,6 +7,10 @@
 //        extra flags: pinned  = publish sensor_msgs::PointCloud2_<PinnedAllocator> (kernels store into output.data)
 //   d2pc_replay dispimage <in.f32> <w> <h> 32FC1 <out.bin> f=<px> T=<m> min_disparity=<d> [compact] [pinned] [step=N]
 //        the stereo_msgs/DisparityImage callback (hpp:65 TODO): calibration from the message
+//   d2pc_replay both <in.raw> <w> <h> <mono8|mono16> <out.bin> di=<in.f32> diw=<w> dih=<h> f=<px> T=<m> min_disparity=<d> [compact] [pinned]
+//        ONE node with both topics live: DisparityImageCb, then DisparityCb, then DisparityImageCb again.  Writes the
+//        DisparityCb cloud to <out.bin> and the second DisparityImage cloud to <out.bin>.di -- the two calibrations
+//        (stereoRectify's Q_ and the message's f, T, min_disparity) must not leak into each other
 //   d2pc_replay latency <in.raw> <w> <h> <mono8|mono16> <frames> [compact] [pinned]
 //        per-frame wall time of DisparityCb over <frames> calls (median, p10, p90 in microseconds)
 // <in.raw> holds the sensor_msgs/Image data bytes (row-major, step = w*bpp).
@@ -128,6 +132,39 @@ int main(int argc, char **argv) {
       auto call = [&](auto &node) { node.DisparityImageCb(dm); };
       return has_flag(argc, argv, "pinned") ? run_node<d2pc_shim::PinnedMsgs>(argc, argv, argv[6], call)
                                             : run_node<d2pc_shim::Msgs>(argc, argv, argv[6], call);
+    }
+    if (cmd == "both") {
+      auto dm = std::make_shared<d2pc_shim::DisparityImage>();
+      dm->header = img->header;
+      dm->image.encoding = "32FC1";
+      const char *di_path = nullptr;
+      for (int i = 7; i < argc; ++i) {
+        if (!strncmp(argv[i], "di=", 3)) di_path = argv[i] + 3;
+        if (!strncmp(argv[i], "diw=", 4)) dm->image.width = uint32_t(atoi(argv[i] + 4));
+        if (!strncmp(argv[i], "dih=", 4)) dm->image.height = uint32_t(atoi(argv[i] + 4));
+        if (!strncmp(argv[i], "f=", 2)) dm->f = float(atof(argv[i] + 2));
+        if (!strncmp(argv[i], "T=", 2)) dm->T = float(atof(argv[i] + 2));
+        if (!strncmp(argv[i], "min_disparity=", 14)) dm->min_disparity = float(atof(argv[i] + 14));
+      }
+      if (!di_path) { fprintf(stderr, "both: di=<file> missing\n"); return 2; }
+      dm->image.step = dm->image.width * 4u;
+      dm->image.data = slurp(di_path);
+      const std::string di_out = std::string(argv[6]) + ".di";
+      auto run = [&](auto tag) {
+        typedef decltype(tag) M;
+        std::vector<typename M::PointCloud2> got;
+        d2pc::Disparity2PCloudT<M> node(
+            params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { got.push_back(pc); }, 0, nullptr,
+            has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false, true);
+        node.DisparityImageCb(dm);
+        node.DisparityCb(img);
+        node.DisparityImageCb(dm);
+        if (got.size() != 3) { fprintf(stderr, "expected three clouds, got %zu\n", got.size()); return 3; }
+        write_cloud(argv[6], got[1]);
+        write_cloud(di_out.c_str(), got[2]);
+        return 0;
+      };
+      return has_flag(argc, argv, "pinned") ? run(d2pc_shim::PinnedMsgs()) : run(d2pc_shim::Msgs());
     }
     if (cmd == "latency") {
       const int frames = atoi(argv[6]);

@@ -199,7 +199,7 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale,
  * receives the number of points of frame f.  All device pointers must belong
  * to the context's device; d_out_points must be 16-byte aligned -- 128-byte
  * alignment (of the base and of out_frame_stride_points*16) keeps every wave
- * store on whole 64-byte memory requests; a base 16 bytes off costs ~20 %.
+ * store on whole 64-byte memory requests (a base that is only 16-byte aligned is slower).
  * Does not synchronise.
  *
  * COMPACT launches in flight at once: calls on ONE stream are ordered and share
@@ -295,21 +295,19 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
  * kernel that works tile by tile: the bit-sliced median of the tile, then the
  * tile's points straight from the filtered bytes in LDS -- for stereoRectify's Q
  * through a per-block table of 1/W and Z over the 256 byte values.  The filtered
- * frames never reach memory; 16 x 4K: 594 us against 818 us for the two launches
- * (profiles/r02_median_bitsliced.txt).  Everything else -- COMPACT mode, small
- * launches -- is the filter launch followed by the reprojection
- * launch.  The results are the same bytes either way.
+ * frames never reach memory.  Everything else -- small launches -- is the filter
+ * launch followed by the reprojection launch.  The results are the same bytes
+ * either way (measurements: DESIGN.md section 5).
  * Tuning "callback_fused": 1 (default) as described; 0 always two launches.
- * (Round 2 also built this overlap as ONE persistent kernel whose blocks switched
- * between filter tiles and reprojection tiles and handed frames over in-kernel;
- * it was 1.4x slower than two launches and has been removed: DESIGN.md section 9.)
  * "callback_chunks" (default 1 = off) cuts a two-launch batch into chunks
- * pipelined over two internal streams: the two kernels side by side finish only
- * 8-15 % sooner than back to back and every cross-stream dependency costs ~20 us,
- * so it ranged from +8 % to -10 % (profiles/r02_callback_overlap.txt).
- * In the two-launch form the filtered frames live in context-owned scratch
- * (grown on demand, so the first call of a size is not capturable; under stream
- * capture the call runs in order on `stream`); the one-kernel form needs none.
+ * pipelined over two internal streams (it did not pay reliably: DESIGN.md section 9);
+ * such calls share those streams and are serialised against each other.
+ * In the two-launch form the filtered frames live in a scratch buffer that belongs
+ * to the calling stream's work (one per stream in flight, like the compaction
+ * state: double-buffered use on two streams is safe); it is grown on demand, so
+ * before a capture reserve it with d2pc_reserve_mono (or run the batch size
+ * once); under stream capture the call runs in order on `stream`.  The
+ * one-kernel form needs no scratch.
  */
 int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int dtype, int width, int height,
                              size_t row_stride_bytes, size_t frame_stride_bytes, int n_frames,
@@ -326,9 +324,8 @@ int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int dtype, int 
  * D2H copy, no bounce through the runtime's staging buffers.  A pinned `disp`
  * / `image` is read by the reprojection kernel in place when that kernel is the
  * first to touch it (PARITY, no median, no mono16 rescale: the inbound reads
- * then overlap the outbound stores on the full-duplex link -- one 4K fp32 frame
- * 2.99 -> 2.53 ms, one native frame 128 -> 115 us); otherwise it makes the
- * upload one DMA.  Pageable buffers keep working as before.
+ * then overlap the outbound stores on the full-duplex link); otherwise it makes
+ * the upload one DMA.  Pageable buffers keep working as before.
  * host/pinned_allocator.hpp wraps these two in a caching std::allocator so that
  * sensor_msgs::PointCloud2_<Alloc>::data can be such a buffer.
  */
@@ -369,6 +366,16 @@ int d2pc_pipeline_release(d2pc_ctx *ctx, int slot);
  * later).  Needed before a capture; optional otherwise (buffers grow on demand). */
 int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames);
 
+/* d2pc_process_mono_device's counterpart of d2pc_reserve: guarantees one free scratch buffer for the two-launch
+ * form of a batch of n_frames frames of width x height (dtype D2PC_DTYPE_U8 or D2PC_DTYPE_MONO16) and, in COMPACT
+ * mode, the compaction state as d2pc_reserve does -- so that the call can be captured without having run once. */
+int d2pc_reserve_mono(d2pc_ctx *ctx, int dtype, int width, int height, int n_frames);
+
+/* Buffers that a stream capture baked into a graph (compaction state, callback scratch) belong to that graph and are
+ * never reused.  Call this once every graph captured from this context's launches has been destroyed: the buffers
+ * return to the context's pools.  Buffers of graphs never take away from the 8 per pool that eager launches use. */
+int d2pc_release_graph_buffers(d2pc_ctx *ctx);
+
 /* After the streams of the context's COMPACT d2pc_process_device calls have been
  * synchronised: D2PC_ERR_INTERNAL if a hand-off wait of the single-pass kernel
  * ran out of its time budget (default 4 s, tuning "spin_timeout_ms") in the
@@ -378,6 +385,36 @@ int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames);
  * compact_algo = 1.  d2pc_process* (synchronous) does that relaunch itself;
  * d2pc_pipeline_collect reports the frame as D2PC_ERR_INTERNAL. */
 int d2pc_check_async_error(d2pc_ctx *ctx);
+
+/*
+ * Counters of the single-pass compaction (compact_algo 2), summed over the context's launches since creation or
+ * d2pc_compact_stats_reset -- the production build's view of the in-launch hand-off (the reference has only
+ * printf breadcrumbs, cpp:47-91).  Call after synchronising the streams that carried the launches.
+ *   launches           single-pass launches
+ *   tiles              tiles they served (each takes one ticket and needs the counts of its predecessors)
+ *   failed_polls       looks at a predecessor's count that found it unpublished; failed_polls / tiles is the
+ *                      hand-off's health: ~0.1 on an idle device, more when predecessors are delayed
+ *   wait_us            time the control waves spent in such waits, summed over all blocks (divide by the number
+ *                      of resident blocks for wall time)
+ *   timeouts           launches in which a wait ran out of its budget (d2pc_check_async_error)
+ *   twopass_fallbacks  synchronous host calls (d2pc_process*) that reran such a launch with the two-pass form
+ */
+typedef struct d2pc_compact_stats_t {
+  uint32_t struct_size;   /* = sizeof(d2pc_compact_stats_t), set by the caller */
+  uint32_t reserved;
+  uint64_t launches, tiles, failed_polls, wait_us, timeouts, twopass_fallbacks;
+} d2pc_compact_stats_t;
+int d2pc_compact_stats(d2pc_ctx *ctx, d2pc_compact_stats_t *out);
+int d2pc_compact_stats_reset(d2pc_ctx *ctx);
+
+/*
+ * Device calibration for benchmarks: a plain fill of `bytes` bytes and a plain copy (16 bytes per lane, 1 KiB per
+ * wave instruction), asynchronous on `stream`.  bench.py times them in the same run as the reprojection kernel,
+ * so its fraction of the 8 TB/s specification can also be read against what THIS device gives a kernel that only
+ * streams.  Buffers 16-byte aligned, `bytes` a multiple of 16, source and destination disjoint.
+ */
+int d2pc_membench_fill(d2pc_ctx *ctx, void *d_dst, size_t bytes, void *stream);
+int d2pc_membench_copy(d2pc_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, void *stream);
 
 /*
  * SURVEY.md section 8(f) #4 -- the inner loop of the sibling node's

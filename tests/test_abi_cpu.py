@@ -206,3 +206,47 @@ def test_stereorectify_flavours():
         assert q[11] == 713.5 and abs(q[14] - 1 / 0.09) < 1e-12 and q[15] == 0.0 and np.signbit(q[15])
     with pytest.raises(d2pc.D2pcError):
         d2pc.make_q_flavour(flavour=7, **d)
+
+
+def test_pinned_buffer_memory_lives_as_long_as_any_view(monkeypatch):
+    """capi.PinnedBuffer: the numpy views own the allocation (advisor, round 2: a temporary
+    PinnedBuffer(...).array used to be freed at once and handed d2pc_process a dangling pointer).
+    Counting stand-ins replace the two ABI calls -- there is no GPU here."""
+    import gc
+
+    class _Lib:
+        def __init__(self):
+            self.blocks, self.freed = {}, []
+
+        def d2pc_host_alloc(self, n):
+            b = ctypes.create_string_buffer(n)
+            self.blocks[ctypes.addressof(b)] = b
+            return ctypes.addressof(b)
+
+        def d2pc_host_free(self, p):
+            self.freed.append(p)
+
+    lib = _Lib()
+    monkeypatch.setattr(capi, "load_library", lambda: lib)
+    view = capi.PinnedBuffer((4, 4), np.float32).array  # the owner object is a temporary
+    addr = view.ctypes.data
+    gc.collect()
+    assert lib.freed == [], "memory freed while a view of it is alive"
+    view[:] = 7.0  # still writable memory of the stand-in allocation
+    assert np.frombuffer(lib.blocks[addr], dtype=np.float32, count=16).tolist() == [7.0] * 16
+    tail = view[2:]
+    del view
+    gc.collect()
+    assert lib.freed == [], "a slice keeps the allocation too"
+    del tail
+    gc.collect()
+    assert lib.freed == [addr]
+    # close() only drops the owner's reference
+    pb = capi.PinnedBuffer(8, np.uint32)
+    keep = pb.array
+    pb.close()
+    gc.collect()
+    assert pb.ptr is None and pb.array is None and len(lib.freed) == 1
+    del keep
+    gc.collect()
+    assert len(lib.freed) == 2 and not pb.alive

@@ -259,3 +259,92 @@ def test_async_error_check_is_per_state_buffer():
         assert np.array_equal(idx, wi)
         assert_points_close(pts, wp, max_ulp=1)
     assert int(counts[0]) == len(oracle.reproject_compact(big[0], q, border=40)[0])
+
+
+def test_many_captures_never_starve_eager_launches_and_buffers_can_be_released():
+    """Advisor, round 2: a captured buffer was never released, and after 8 captures every COMPACT call of the
+    context failed.  Buffers owned by graphs now come on top of the 8 eager ones, and d2pc_release_graph_buffers
+    hands them back once the graphs are gone."""
+    q = d2pc.make_q()
+    frames = [synth_disparity(2, f, 320, 240, "holes") for f in range(2)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        b = _batch(ctx, frames, want_index=True)
+        graphs = []
+        for _ in range(11):   # more captures than the pool used to hold
+            ctx.reserve(320, 240, 2)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                b.launch()
+            graphs.append(g)
+        b.launch()            # an eager launch still gets a buffer
+        eager = b.results()
+        for g in graphs:      # every graph kept its own state
+            b.points.fill_(0)
+            b.counts.fill_(0)
+            g.replay()
+            rep = b.results()
+            for (p1, i1), (p2, i2) in zip(eager, rep):
+                assert np.array_equal(i1, i2) and np.array_equal(p1.view(np.uint32), p2.view(np.uint32))
+        del graphs, g
+        torch.cuda.synchronize()
+        ctx.release_graph_buffers()
+        b.launch()
+        again = b.results()
+        ctx.check_async_error()
+    for f, (pts, idx) in enumerate(again):
+        wp, wi = oracle.reproject_compact(frames[f], q, border=40)
+        assert np.array_equal(idx, wi)
+        assert_points_close(pts, wp, max_ulp=1)
+
+
+def test_compact_stats_count_the_single_pass_launches():
+    """d2pc_compact_stats: production counters of the single pass (tiles served, failed polls, wait time), folded by
+    the next launch's state clear; the two-pass form leaves them alone."""
+    q = d2pc.make_q()
+    frames = [synth_disparity(3, 700 + f, 1920, 1080, "holes") for f in range(8)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=2) as ctx:
+        b = _batch(ctx, frames, want_index=True)
+        tiles = 8 * -(-d2pc.roi_points(1920, 1080, 40) // 2048)
+        st = ctx.compact_stats()
+        assert st["launches"] == 0 and st["tiles"] == 0
+        for _ in range(5):
+            b.launch()
+        torch.cuda.synchronize()
+        st = ctx.compact_stats()
+        assert st["launches"] == 5 and st["tiles"] == 5 * tiles and st["timeouts"] == 0 and st["twopass_fallbacks"] == 0
+        assert st["failed_polls"] < 50 * st["tiles"]
+        assert (st["wait_us"] > 0) == (st["failed_polls"] > 0)
+        st2 = ctx.compact_stats()            # reading does not consume
+        assert st2 == st
+        ctx.compact_stats_reset()
+        assert ctx.compact_stats()["launches"] == 0
+        b.launch()
+        torch.cuda.synchronize()
+        assert ctx.compact_stats()["tiles"] == tiles
+        res = b.results()
+    wp, wi = oracle.reproject_compact(frames[3], q, border=40)
+    assert np.array_equal(res[3][1], wi)
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=1) as ctx:
+        b = _batch(ctx, frames[:2], want_index=False)
+        b.launch()
+        torch.cuda.synchronize()
+        assert ctx.compact_stats()["launches"] == 0
+
+
+def test_membench_kernels_fill_and_copy():
+    """The calibration kernels bench.py times next to the reprojection: every byte written / copied."""
+    with d2pc.Context(q=d2pc.make_q()) as ctx:
+        n = (1 << 20) + 48
+        buf = torch.zeros(2 * n, dtype=torch.uint8, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        ctx.membench_fill(buf.data_ptr(), n, s)
+        torch.cuda.synchronize()
+        host = buf.cpu().numpy()
+        want = np.tile(np.array([1.0, 2.0, 3.0, 1.0], dtype=np.float32).view(np.uint8), n // 16)
+        assert np.array_equal(host[:n], want) and not host[n:].any()
+        src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
+        ctx.membench_copy(src.data_ptr(), buf.data_ptr() + n, n, s)
+        torch.cuda.synchronize()
+        assert torch.equal(buf[n:], src)
+        with pytest.raises(d2pc.D2pcError):
+            ctx.membench_copy(buf.data_ptr(), buf.data_ptr() + 16, n, s)   # overlap

@@ -192,6 +192,46 @@ def test_disparity_image_callback_takes_its_calibration_from_the_message(replay,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["parity", "compact"])
+def test_both_topics_live_keep_their_own_calibration(replay, tmp_path, mode):
+    """Advisor, round 2: DisparityImageCb used to overwrite the node's Q_ and min_disparity, so every later
+    /disparity callback reprojected with the message's calibration.  One node, DisparityImageCb -> DisparityCb ->
+    DisparityImageCb: the mono8 cloud must be the stereoRectify-Q cloud (hpp:104), the DisparityImage cloud the
+    message's, and in COMPACT mode the message's min_disparity must not thin the /disparity cloud."""
+    import disparity_to_point_cloud_amd as d2pc
+
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(200, 300)).astype(np.uint8)       # /disparity, mono8: d = median/8 <= 31.9
+    img[rng.random(img.shape) < 0.3] = 0
+    disp = rng.uniform(0.0, 64.0, size=(160, 240)).astype(np.float32)  # /disparity_image, another size
+    disp[rng.random(disp.shape) < 0.2] = 0.0
+    f, T, dmin = 412.5, 0.12, 40.0   # dmin above every 8-bit disparity: a leak would empty the mono8 cloud
+    di = tmp_path / "di.f32"
+    di.write_bytes(disp.tobytes())
+    extra = [f"di={di}", "diw=240", "dih=160", f"f={f}", f"T={T}", f"min_disparity={dmin}"]
+    if mode == "compact":
+        extra.append("compact")
+    p, dst = _run(replay, "both", img, "mono8", tmp_path, *extra)
+    assert p.returncode == 0, p.stderr
+    _, pts = _cloud(dst)
+    q = d2pc.make_q_flavour()
+    med = oracle.median_u8(img, 11)
+    if mode == "parity":
+        want = oracle.reproject(med, q, border=40, scale=0.125)
+    else:
+        want, _ = oracle.reproject_compact(med, q, border=40, scale=0.125)
+        assert len(want) > 1000
+    assert_points_close(pts, want, max_ulp=1, rel=1e-5, what="DisparityCb after DisparityImageCb")
+    _, pts_di = _cloud(tmp_path / "out.bin.di")
+    qd = d2pc.make_q_disparity_image(np.float32(f), np.float32(T), 376.0, 240.0)
+    if mode == "parity":
+        want_di = oracle.reproject(disp, qd, border=40)
+    else:
+        want_di, _ = oracle.reproject_compact(disp, qd, border=40, min_disparity=dmin)
+    assert_points_close(pts_di, want_di, max_ulp=1, rel=1e-5, what="DisparityImageCb after DisparityCb")
+
+
+@pytest.mark.gpu
 def test_disparity_image_callback_rejects_other_encodings(replay, tmp_path):
     img = np.zeros((100, 100), dtype=np.uint8)
     p, _ = _run(replay, "dispimage", img, "mono8", tmp_path, "f=400", "T=0.1")

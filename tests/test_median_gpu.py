@@ -421,3 +421,93 @@ def test_callback_body_at_the_benchmark_size_one_kernel_equals_two_launches():
     for f in (0, 7, 15):
         want = oracle.reproject(oracle.median_u8(src[f].cpu().numpy(), 11), q, border=40, scale=0.125)
         assert_points_close(res[f][0], want, max_ulp=1, rel=1e-5, what=f"frame {f}")
+
+
+@pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
+@pytest.mark.parametrize("dtype", ["u8", "mono16"])
+def test_process_mono_device_two_launch_form_on_two_streams_in_flight(mode, dtype):
+    """Advisor, round 2: the two-launch form of d2pc_process_mono_device kept its filtered / rescaled frames in ONE
+    context-wide scratch, so two calls in flight on different streams overwrote each other's frames.  Two different
+    batches, two streams, no synchronisation in between, many rounds: each must come out as its own."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    q = d2pc.make_q()
+    rng = np.random.default_rng(90 + mode)
+    n, h, w = 5, 480, 752
+    sets = []
+    for _ in range(2):
+        if dtype == "u8":
+            imgs = rng.integers(0, 256, size=(n, h, w)).astype(np.uint8)
+            sets.append((imgs, torch.from_numpy(imgs).cuda(), imgs))
+        else:
+            imgs = rng.integers(0, 65536, size=(n, h, w)).astype(np.uint16)
+            sets.append((imgs, torch.from_numpy(imgs.view(np.int16)).cuda(), np.stack([oracle.mono16_to_mono8(i) for i in imgs])))
+    dt, rs = (d2pc.DTYPE_U8, w) if dtype == "u8" else (d2pc.DTYPE_MONO16, 2 * w)
+    with d2pc.Context(q=q, mode=mode) as ctx:
+        ctx.set_tuning("callback_fused", 0)   # the filter launch + the reprojection launch: the form with scratch
+        bs = [DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True) for _ in range(2)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        for _ in range(10):
+            for (_, src, _), b, s in zip(sets, bs, streams):
+                ctx.process_mono_device(src.data_ptr(), dt, w, h, rs, rs * h, n, 11, 0.125, b.points.data_ptr(),
+                                        b.index.data_ptr(), b.stride, b.counts.data_ptr(), s.cuda_stream)
+        torch.cuda.synchronize()
+        ctx.check_async_error()
+        res = [b.results() for b in bs]
+    for (_, _, m8), r in zip(sets, res):
+        for f in range(n):
+            filt = oracle.median_u8(m8[f], 11)
+            pts, idx = r[f]
+            if mode == d2pc.MODE_PARITY:
+                want = oracle.reproject(filt, q, border=40, scale=0.125)
+            else:
+                want, wi = oracle.reproject_compact(filt, q, border=40, scale=0.125)
+                assert np.array_equal(idx, wi)
+            assert_points_close(pts, want, max_ulp=1, rel=1e-5, what=f"frame {f}")
+
+
+@pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
+def test_process_mono_device_is_capturable_after_reserve_mono(mode):
+    """d2pc_reserve_mono: the two-launch form (here: MONO16 + COMPACT-or-PARITY with callback_fused = 0) captured
+    WITHOUT a warm-up call of that size; without the reservation the capture is refused cleanly."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    q = d2pc.make_q()
+    rng = np.random.default_rng(12)
+    imgs = rng.integers(0, 65536, size=(3, 300, 412)).astype(np.uint16)
+    n, h, w = imgs.shape
+    src = torch.from_numpy(imgs.view(np.int16)).cuda()
+    with d2pc.Context(q=q, mode=mode) as ctx:
+        ctx.set_tuning("callback_fused", 0)
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
+
+        def call():
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_MONO16, w, h, 2 * w, 2 * w * h, n, 11, 0.125,
+                                    b.points.data_ptr(), b.index.data_ptr(), b.stride, b.counts.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        err = None
+        with torch.cuda.graph(g):
+            try:
+                call()
+            except d2pc.D2pcError as e:
+                err = e
+        assert err is not None and "reserve" in str(err)
+        ctx.reserve_mono(d2pc.DTYPE_MONO16, w, h, n)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            call()
+        for _ in range(2):
+            b.points.fill_(0)
+            b.counts.fill_(0)
+            g.replay()
+        res = b.results()
+        ctx.check_async_error()
+    for f in range(n):
+        filt = oracle.median_u8(oracle.mono16_to_mono8(imgs[f]), 11)
+        if mode == d2pc.MODE_PARITY:
+            want = oracle.reproject(filt, q, border=40, scale=0.125)
+        else:
+            want, wi = oracle.reproject_compact(filt, q, border=40, scale=0.125)
+            assert np.array_equal(res[f][1], wi)
+        assert_points_close(res[f][0], want, max_ulp=1, what=f"captured frame {f}")

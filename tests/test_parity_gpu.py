@@ -407,6 +407,26 @@ def test_pinned_output_is_written_directly_and_matches_the_staged_path(q_default
     idx_buf.close()
 
 
+def test_pinned_array_from_a_temporary_owner_stays_valid(q_default):
+    """The docstring's pattern `out=PinnedBuffer(...).array`: the owner object dies at once, the array keeps the
+    pinned allocation (advisor, round 2: it used to be freed, and the kernels then stored into freed memory)."""
+    import gc
+
+    disp = synth_disparity(2, 9, 752, 480, "holes")
+    cap = d2pc.roi_points(752, 480, 40)
+    out = d2pc.PinnedBuffer((cap, 4), np.float32).array
+    gc.collect()
+    filler = [d2pc.PinnedBuffer((cap, 4), np.float32) for _ in range(3)]  # would reuse a freed block
+    for f in filler:
+        f.array[:] = np.float32(3.0)
+    with ctx_for(q_default) as ctx:
+        want = ctx.process(disp)
+        got = ctx.process(disp, out=out)
+        assert got.ctypes.data == out.ctypes.data
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert all(np.all(f.array == np.float32(3.0)) for f in filler)
+
+
 @pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
 def test_pinned_input_is_read_in_place(mode, q_default):
     """A frame that lies in pinned host memory is read by the first kernel straight from there (no staging copy):
