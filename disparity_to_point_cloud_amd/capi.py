@@ -156,6 +156,16 @@ def load_library():
     except Exception:  # torch is plumbing only; the ABI works without it
         pass
     L = ctypes.CDLL(path)
+    if _LIB_NAME != "libd2pc.so":
+        # tuning / A-B builds (tools only) may predate an entry point: calling a missing one raises
+        class _Missing:
+            argtypes = restype = None
+
+            def __call__(self, *a):
+                raise AttributeError(f"{_LIB_NAME} does not export this entry point")
+        for name in ABI_SYMBOLS:
+            if not hasattr(L, name):
+                setattr(L, name, _Missing())
     vp, cp = ctypes.c_void_p, ctypes.c_char_p
     dp = ctypes.POINTER(ctypes.c_double)
     L.d2pc_abi_version.restype = ctypes.c_int

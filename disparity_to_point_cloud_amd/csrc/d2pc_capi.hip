@@ -100,8 +100,7 @@ struct d2pc_ctx {
   void *d_cvt = nullptr;     size_t cvt_cap = 0;   // mono16 -> mono8 (cpp:50)
   uint32_t *d_counts = nullptr;
   uint32_t *h_counts = nullptr;  // pinned
-  CompactStats *d_stats = nullptr;  // single-pass counters, accumulated by k_state_clear (d2pc_compact_stats)
-  CompactStats stats_host{};        // counters of state buffers that were freed before a later launch folded them
+  CompactStats *d_stats = nullptr;  // single-pass counters, added to by the launches' blocks (d2pc_compact_stats)
   int membench_blocks_per_cu = 8;
   // d2pc_process_mono_device: two internal streams + scratch for the filtered frames
   int cb_fused = 1;              // d2pc_process_mono_device, PARITY: median + points in one kernel, tile by tile (k_callback_bs:
@@ -273,17 +272,6 @@ int state_alloc(d2pc_ctx *ctx, const BufPool *pool, StateBuf &b, size_t need, si
   if ((b.p || b.p2) && b.pending) {
     D2PC_HIP(ctx, hipEventSynchronize(b.done));  // its last launch still reads and writes it
     b.pending = false;
-  }
-  if (b.p && b.algo == 2 && b.cap < need && b.cap >= sizeof(StateHeader)) {
-    // a compaction state about to be replaced: keep the counters its last single-pass launch left in the header
-    StateHeader h;
-    D2PC_HIP(ctx, hipMemcpy(&h, b.p, sizeof h, hipMemcpyDeviceToHost));
-    ctx->stats_host.launches += h.launches;
-    ctx->stats_host.tiles += h.tiles;
-    ctx->stats_host.failed_polls += h.failed_polls;
-    ctx->stats_host.wait_ticks += h.wait_ticks;
-    ctx->stats_host.timeouts += h.launches && h.timeout ? 1 : 0;
-    b.algo = 0;
   }
   int st = grow(ctx, &b.p, &b.cap, need);
   if (st == D2PC_OK && need2) st = grow(ctx, &b.p2, &b.cap2, need2);
@@ -935,44 +923,25 @@ int d2pc_check_async_error(d2pc_ctx *ctx) {
   return D2PC_OK;
 }
 
-// Single-pass counters: what the launches' blocks left in the state headers (folded into ctx->d_stats by the NEXT
-// launch's k_state_clear) plus the headers not folded yet.  The caller has synchronised its streams.
+// Single-pass counters: the sum of the slots the launches' blocks added to.  The caller has synchronised its streams.
 int d2pc_compact_stats(d2pc_ctx *ctx, d2pc_compact_stats_t *out) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
   if (!out || out->struct_size != sizeof(d2pc_compact_stats_t)) return fail(ctx, D2PC_ERR_INVALID_ARG, "bad d2pc_compact_stats_t");
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
-  CompactStats acc;
-  D2PC_HIP(ctx, hipMemcpy(&acc, ctx->d_stats, sizeof acc, hipMemcpyDeviceToHost));
-  acc.launches += ctx->stats_host.launches;
-  acc.tiles += ctx->stats_host.tiles;
-  acc.failed_polls += ctx->stats_host.failed_polls;
-  acc.wait_ticks += ctx->stats_host.wait_ticks;
-  acc.timeouts += ctx->stats_host.timeouts;
-  auto add_header = [&](const StateBuf &b) -> int {
-    if (!b.p || b.cap < sizeof(StateHeader)) return D2PC_OK;
-    StateHeader h;
-    D2PC_HIP(ctx, hipMemcpy(&h, b.p, sizeof h, hipMemcpyDeviceToHost));
-    if (!h.launches) return D2PC_OK;  // never used by the single pass, or folded and not relaunched
-    acc.launches += h.launches;
-    acc.tiles += h.tiles;
-    acc.failed_polls += h.failed_polls;
-    acc.wait_ticks += h.wait_ticks;
-    acc.timeouts += h.timeout ? 1 : 0;
-    return D2PC_OK;
-  };
-  for (const StateBuf *b : ctx->states.bufs) {
-    int st = add_header(*b);
-    if (st != D2PC_OK) return st;
-  }
-  for (int i = 0; i < ctx->pipe_depth; ++i) {
-    int st = add_header(ctx->slots[i].st);
-    if (st != D2PC_OK) return st;
+  std::vector<unsigned char> raw(sizeof(CompactStats));
+  D2PC_HIP(ctx, hipMemcpy(raw.data(), ctx->d_stats, sizeof(CompactStats), hipMemcpyDeviceToHost));
+  const CompactStats &acc = *reinterpret_cast<const CompactStats *>(raw.data());
+  uint64_t tiles = 0, polls = 0, ticks = 0;
+  for (const CompactStats::Slot &sl : acc.slot) {
+    tiles += sl.tiles;
+    polls += sl.failed_polls;
+    ticks += sl.wait_ticks;
   }
   out->launches = acc.launches;
-  out->tiles = acc.tiles;
-  out->failed_polls = acc.failed_polls;
-  out->wait_us = acc.wait_ticks / (kSpinTicksPerMs / 1000u);
+  out->tiles = tiles;
+  out->failed_polls = polls;
+  out->wait_us = ticks / (kSpinTicksPerMs / 1000u);
   out->timeouts = acc.timeouts;
   out->twopass_fallbacks = ctx->n_twopass_fallbacks;
   return D2PC_OK;
@@ -983,23 +952,7 @@ int d2pc_compact_stats_reset(d2pc_ctx *ctx) {
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
   D2PC_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(CompactStats)));
-  // the counters of each buffer's last launch (the timeout flag stays: d2pc_check_async_error reads it)
-  auto clear_header = [&](const StateBuf &b) -> int {
-    if (!b.p || b.cap < sizeof(StateHeader)) return D2PC_OK;
-    D2PC_HIP(ctx, hipMemset(static_cast<char *>(b.p) + offsetof(StateHeader, launches), 0,
-                            offsetof(StateHeader, diag) - offsetof(StateHeader, launches)));
-    return D2PC_OK;
-  };
-  for (const StateBuf *b : ctx->states.bufs) {
-    int st = clear_header(*b);
-    if (st != D2PC_OK) return st;
-  }
-  for (int i = 0; i < ctx->pipe_depth; ++i) {
-    int st = clear_header(ctx->slots[i].st);
-    if (st != D2PC_OK) return st;
-  }
   ctx->n_twopass_fallbacks = 0;
-  ctx->stats_host = CompactStats{};
   return D2PC_OK;
 }
 
@@ -1027,6 +980,16 @@ int d2pc_membench_copy(d2pc_ctx *ctx, const void *d_src, void *d_dst, size_t byt
                                      static_cast<hipStream_t>(stream)));
   return D2PC_OK;
 }
+
+#if defined(D2PC_CLEAR_WITH_MEMSET) && D2PC_CLEAR_WITH_MEMSET
+// experiment build only (tools/graph_memset_probe.py): the raw accumulators, pad[] included
+int d2pc_debug_read_stats(d2pc_ctx *ctx, void *out64) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  D2PC_HIP(ctx, hipMemcpy(out64, ctx->d_stats, sizeof(CompactStats), hipMemcpyDeviceToHost));
+  return D2PC_OK;
+}
+#endif
 
 #ifdef D2PC_DIAG
 // diagnostic build only: copy the 128-byte state header (phase timers) out

@@ -84,23 +84,29 @@ enum : int { QK_GENERAL = 0, QK_STEREO = 1 };
 //   the 16 B per tile hold one u64 granule (single pass) or 4 x u32 wave counts (two-pass)
 //   group_acc = (tiles arrived << 32) | sum of their point counts
 //   granule   = kGranuleTag | point count of one tile
+struct CompactStats;
 struct StateHeader {
   uint32_t timeout;       // set to 1 if a bounded spin expired
   uint32_t pad;
-  // production counters of the single pass, summed over the launch's blocks at their exit (one atomic each per
-  // block); k_state_clear folds them into the context's CompactStats before it zeroes the header for the next launch
-  unsigned long long launches;      // 1 (written by k_state_clear)
-  unsigned long long tiles;         // tiles served
-  unsigned long long failed_polls;  // polls of a predecessor's count that found it not yet published
-  unsigned long long wait_ticks;    // time control waves spent in such waits, 100 MHz ticks, summed over blocks
+  CompactStats *stats;    // the context's production counters (written by k_state_clear for the launch behind it)
   // diagnostic build only (-DD2PC_DIAG): shader-clock sums over all tiles
   unsigned long long diag[7];  // iterations, spins, t_compute, t_ticket, t_wait, t_scatter, t_total
-  unsigned long long pad2[4];
+  unsigned long long pad2[7];
 };
 static_assert(sizeof(StateHeader) == 128, "the header is one 128-byte line");
-// Accumulated over a context's single-pass launches (device memory, never cleared by a launch).
+// Production counters of a context's single-pass launches (device memory, never cleared by a launch).  Every
+// block adds its share once, at its exit, to slot blockIdx % kStatSlots: 768-1024 blocks finishing together on ONE
+// word serialise at the memory side and cost 40-60 us per launch (profiles/r03_ab_counters.txt); spread over
+// 64 lines they cost nothing.  The host sums the slots.
+constexpr int kStatSlots = 64;
 struct CompactStats {
-  unsigned long long launches, tiles, failed_polls, wait_ticks, timeouts, pad[3];
+  struct Slot {
+    unsigned long long tiles;         // tiles served
+    unsigned long long failed_polls;  // polls of a predecessor's count that found it not yet published
+    unsigned long long wait_ticks;    // time control waves spent in such waits, 100 MHz ticks, summed over blocks
+    unsigned long long pad[13];       // a slot is one 128-byte line
+  } slot[kStatSlots];
+  unsigned long long launches, timeouts, dbg[2];
 };
 constexpr uint32_t kFrameTicketBytes = 256;   // the ticket word has a 256-B block to itself
 constexpr uint32_t kGroupAccStride = 128;     // one group accumulator per 128-B line

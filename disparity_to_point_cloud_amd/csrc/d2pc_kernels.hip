@@ -57,6 +57,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifndef D2PC_CLEAR_WITH_MEMSET
 #define D2PC_CLEAR_WITH_MEMSET 0
 #endif
+// A/B switch for the production counters of the single pass (tools/ab.py): 0 removes them
+#ifndef D2PC_ONEPASS_STATS
+#define D2PC_ONEPASS_STATS 1
+#endif
 template <class T>
 __device__ __forceinline__ T ld(const T *p) {
 #if D2PC_LOAD_NT
@@ -505,10 +509,12 @@ __device__ __forceinline__ void backoff(uint32_t spins) {
   for (uint32_t j = 0; j < n; ++j) __builtin_amdgcn_s_sleep(1);
 }
 
-// What a control wave's waits cost, summed over the block's tiles (wave-uniform).
+// What a control wave's waits cost, summed over the block's tiles.  The sums live in LDS (three words of the
+// block), not in registers: the single pass has no scalar register to spare -- kept in registers, these two
+// counters cost 9 % (16 x 4K) to 25 % (32 x 1080p) of the kernel's time through the spills they caused in the
+// workers' loop (profiles/r03_ab_counters.txt).
 struct PollStats {
-  uint32_t failed = 0;  // polls that found the word not ready
-  uint32_t ticks = 0;   // 100 MHz ticks spent in waits that needed more than the first look
+  uint32_t *lds;  // [0] tiles served, [1] failed polls, [2] 100 MHz ticks spent in waits that needed more than one look
 };
 
 // Waits (WAIT) until the 64-bit word at p satisfies `ready`, and returns it.
@@ -542,14 +548,17 @@ __device__ __forceinline__ uint64_t read_counted(const uint64_t *p, bool on, Sta
       if ((spins & 15u) == 0 &&
           (__builtin_amdgcn_s_memrealtime() - t0 > uint64_t(spin_ticks) ||
            __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        if (lane == 0) __hip_atomic_store(&hdr->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && __hip_atomic_exchange(&hdr->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+          atomicAdd(&hdr->stats->timeouts, 1ull);  // the launch's first give-up counts it (d2pc_compact_stats)
         break;
       }
     }
-    if (spins) {  // production counters (d2pc_compact_stats): failed polls and the time they took
-      ps.failed += spins;
-      ps.ticks += uint32_t(__builtin_amdgcn_s_memrealtime() - t0);
+#if D2PC_ONEPASS_STATS
+    if (spins && lane == 0) {  // production counters (d2pc_compact_stats): failed polls and the time they took
+      ps.lds[1] += spins;
+      ps.lds[2] += uint32_t(__builtin_amdgcn_s_memrealtime() - t0);
     }
+#endif
     return v;
   }
 }
@@ -1008,8 +1017,9 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
   __shared__ float s_tile[4 * kStage];
   float *const my_tile = s_tile + (wave < kBlock / 64 ? wave : 0u) * kWaveStage;
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
-  PollStats polls;
-  uint32_t served = 0;  // control wave: tiles this block took
+  __shared__ uint32_t s_stat[3];  // control wave, lane 0: tiles served, failed polls, wait ticks (PollStats)
+  PollStats polls{s_stat};
+  if (tid < 3) s_stat[tid] = 0;  // (ordered before the control wave's first use by the barrier below)
 #ifdef D2PC_DIAG
   // phase timers (shader clock), lane 0 of worker wave 0 and of the control wave; named
   // scalars on purpose: a runtime-indexed array would live in scratch and distort the run
@@ -1061,7 +1071,9 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
           if (lane == 0) s_prefix[slot] = p;
         }
         if (cur != kNoTile && lane == 0) s_next[slot] = tk;
-        served += cur != kNoTile ? 1u : 0u;
+#if D2PC_ONEPASS_STATS
+        if (cur != kNoTile && lane == 0) s_stat[0] += 1u;
+#endif
       } else if (cur != kNoTile) {
         float dc[PXT];
         stage_read<PXT>(dc, my_tile + (it & 3u) * kStage, lane);
@@ -1144,13 +1156,17 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
     // prefix it never obtained), whether or not the frame's last tile has reported its count already
     if (counts && tid == 0 && __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       __hip_atomic_store(counts + f, kCountTimedOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ctl && lane == 0) {  // the block's share of the launch's counters (no-return atomics, once per block)
-      atomicAdd(&hdr->tiles, (unsigned long long)served);
-      if (polls.failed) {
-        atomicAdd(&hdr->failed_polls, (unsigned long long)polls.failed);
-        atomicAdd(&hdr->wait_ticks, (unsigned long long)polls.ticks);
+#if D2PC_ONEPASS_STATS
+    if (ctl && lane == 0) {  // the block's share of the context's counters: no-return atomics, once per block, on the
+                             // block's slot (one word for all blocks serialised the launch's end: d2pc_device.hpp)
+      CompactStats::Slot *sl = hdr->stats->slot + (blockIdx.x % uint32_t(kStatSlots));
+      atomicAdd(&sl->tiles, (unsigned long long)s_stat[0]);
+      if (s_stat[1]) {
+        atomicAdd(&sl->failed_polls, (unsigned long long)s_stat[1]);
+        atomicAdd(&sl->wait_ticks, (unsigned long long)s_stat[2]);
       }
     }
+#endif
   }
 #ifdef D2PC_DIAG
   if (lane == 0 && wave == 0) {
@@ -1161,7 +1177,7 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
     atomicAdd(&hdr->diag[5], tD);
   }
   if (lane == 0 && ctl) {
-    atomicAdd(&hdr->diag[1], (unsigned long long)polls.failed);
+    atomicAdd(&hdr->diag[1], (unsigned long long)s_stat[1]);
     atomicAdd(&hdr->diag[6], tA);  // control: ticket + prefix
   }
 #endif
@@ -1194,31 +1210,37 @@ static hipError_t launch_parity_t(const LaunchArgs &a) {
   return hipGetLastError();
 }
 
-// Zeroes the compaction state ahead of a single-pass launch.  A kernel of our own rather than
-// hipMemsetAsync: see tools/graph_memset_repro.hip and DESIGN.md section 7 for what was observed with a
-// memset node in a captured graph; a plain kernel node has exactly the ordering and cache behaviour of the
-// kernels around it.  Thread 0 first folds the PREVIOUS launch's counters (left in the header by its blocks)
-// into the context's accumulators, then starts the new header with launches = 1.
+// Zeroes the compaction state ahead of a single-pass launch and starts its header (the pointer to the context's
+// counters; one launch counted).  A kernel of our own rather than hipMemsetAsync: captured into a hipGraph, the
+// runtime's memset node left the state UNTOUCHED on replays when the graph was launched on another stream than it
+// was captured on and the host had synchronised in between (the kernel node behind it found all of it dirty:
+// profiles/r03_graph_memset.txt); a plain kernel node has exactly the ordering of the kernels around it.
 __global__ __launch_bounds__(256) void k_state_clear(uint4 *__restrict__ p, uint32_t n16, CompactStats *stats) {
   constexpr uint32_t kHdr16 = uint32_t(sizeof(StateHeader) / 16);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i == 0) {
-    StateHeader *h = reinterpret_cast<StateHeader *>(p);
-    const StateHeader old = *h;
-    if (old.launches) {
-      atomicAdd(&stats->launches, old.launches);
-      atomicAdd(&stats->tiles, old.tiles);
-      atomicAdd(&stats->failed_polls, old.failed_polls);
-      atomicAdd(&stats->wait_ticks, old.wait_ticks);
-      if (old.timeout) atomicAdd(&stats->timeouts, 1ull);
-    }
     StateHeader fresh{};
-    fresh.launches = 1;
-    *h = fresh;
+    fresh.stats = stats;
+    *reinterpret_cast<StateHeader *>(p) = fresh;
+    atomicAdd(&stats->launches, 1ull);
   } else if (i >= kHdr16 && i < n16) {
     p[i] = uint4{0u, 0u, 0u, 0u};
   }
 }
+
+#if D2PC_CLEAR_WITH_MEMSET
+__global__ __launch_bounds__(256) void k_state_verify(const uint4 *__restrict__ p, uint32_t n16, CompactStats *stats) {
+  using gu32 = __attribute__((address_space(1))) const uint32_t;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i == 0) atomicAdd(&stats->dbg[1], 1ull);
+  if (i < n16) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p + i);
+    uint32_t any = 0;
+    for (int k = 0; k < 4; ++k) any |= __hip_atomic_load((gu32 *)(w + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (any) atomicAdd(&stats->dbg[0], 1ull);
+  }
+}
+#endif
 
 template <int DT, int QK, int PXT, bool VEC>
 static hipError_t launch_compact_t(const LaunchArgs &a) {
@@ -1238,6 +1260,10 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
 #if D2PC_CLEAR_WITH_MEMSET  // experiment only (tools/graph_memset_probe.py): round 1's hipMemsetAsync instead of the kernel
     if (getenv("D2PC_TRACE_MEMSET")) fprintf(stderr, "d2pc: hipMemsetAsync(%p, 0, %zu) on stream %p\n", a.state, a.state_bytes, (void *)a.stream);
     if (hipError_t e = hipMemsetAsync(a.state, 0, a.state_bytes, a.stream); e != hipSuccess) return e;
+    // ... followed by a kernel that counts the 16-byte pieces of the state that are NOT zero when it runs
+    // (stats->pad[0]) and the launches it looked at (pad[1]): d2pc_debug_read_stats
+    hipLaunchKernelGGL(k_state_verify, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<const uint4 *>(a.state), n16,
+                       static_cast<CompactStats *>(a.stats));
 #else
     hipLaunchKernelGGL(k_state_clear, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(a.state), n16,
                        static_cast<CompactStats *>(a.stats));

@@ -28,10 +28,10 @@ for pxt in (8,):
         # read the header back: ctx keeps d_state private, so find it via a tiny helper: check_async_error copies the
         # header; we re-read it here through hipMemcpy using the pointer stored at a known offset is not exposed =>
         # use the debug export below.
-        buf = (ctypes.c_ulonglong * 16)()  # the 128-byte StateHeader: flag, launches, tiles, failed_polls, wait_ticks, diag[7]
+        buf = (ctypes.c_ulonglong * 16)()  # the 128-byte StateHeader: flag, stats pointer, diag[7]
         lib.d2pc_debug_read_header.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.d2pc_debug_read_header(ctx.handle, buf)
-        its, spins, wA, wB, wC, wD, cA = [buf[i] for i in range(5, 12)]
+        its, spins, wA, wB, wC, wD, cA = [buf[i] for i in range(2, 9)]
         its = max(its, 1)
         print(f"pxt={pxt:2d} bpc={bpc:2d} kernel={e0.elapsed_time(e1)*1e3:8.1f}us iterations={its} spins/it={spins/its:6.2f} "
               f"cycles/it worker: count={wA/its:6.0f} barrier1={wB/its:6.0f} scan-wait={wC/its:6.0f} loads+scatter={wD/its:6.0f} "

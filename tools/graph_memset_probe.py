@@ -2,8 +2,11 @@
 """Does the LIBRARY's captured single-pass launch replay correctly when the state is zeroed by hipMemsetAsync (round 1)
 instead of k_state_clear (round 2)?  Needs the experiment build:
     make -C disparity_to_point_cloud_amd/csrc variant NAME=memset DEFS=-DD2PC_CLEAR_WITH_MEMSET=1
-    D2PC_LIBRARY_VARIANT=memset D2PC_TRACE_MEMSET=1 python tools/graph_memset_probe.py
-Prints, per replay, the frames' counts against the expected ones and the timeout flag.  GPU box only."""
+    D2PC_LIBRARY_VARIANT=memset python tools/graph_memset_probe.py
+Matrix: capture through torch.cuda.CUDAGraph or through raw HIP calls (ctypes) x host reads of the state header between
+replays (d2pc_check_async_error) or none.  Prints per replay whether the counts came out and the timeout flag.
+GPU box only."""
+import ctypes
 import os
 import sys
 
@@ -17,30 +20,80 @@ from disparity_to_point_cloud_amd.synth import synth_disparity  # noqa: E402
 from disparity_to_point_cloud_amd.torch_api import DeviceBatch  # noqa: E402
 
 print("library:", d2pc.capi.library_path())
+hip = ctypes.CDLL("libamdhip64.so")
+vp = ctypes.c_void_p
+
+
+def ck(e, what):
+    if e != 0:
+        raise RuntimeError(f"{what}: hip error {e}")
+
+
+def dirty(ctx):
+    """(16-byte pieces of the state found non-zero by the verify kernel behind the memset, launches verified)"""
+    buf = (ctypes.c_ulonglong * 1028)()  # CompactStats: 64 slots of 128 bytes, then launches, timeouts, dbg[2]
+    L = d2pc.load_library()
+    L.d2pc_debug_read_stats.argtypes = [vp, vp]
+    L.d2pc_debug_read_stats(ctx.handle, buf)
+    return f"[verify kernel: {buf[1026]} dirty pieces over {buf[1027]} launches]"
+
+
+def flag(ctx):
+    try:
+        ctx.check_async_error()
+        return "clear"
+    except d2pc.D2pcError:
+        return "TIMEOUT FLAG SET"
+
+
 q = d2pc.make_q()
-for (w, h, n) in ((640, 480, 6), (1920, 1080, 8)):
-    frames = [synth_disparity(2, f, w, h, "holes") for f in range(n)]
-    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=2) as ctx:
-        ctx.set_tuning("spin_timeout_ms", 200)
-        b = DeviceBatch(ctx, n, h, w, want_index=True)
-        b.disp.copy_(torch.from_numpy(np.stack(frames)))
-        b.launch()
-        torch.cuda.synchronize()
-        want = b.counts.cpu().numpy().copy()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+w, h, n = 640, 480, 6
+frames = [synth_disparity(2, f, w, h, "holes") for f in range(n)]
+for capture in ("torch", "torch_side", "hip", "hip_null"):
+    for host_reads in (True, False):
+        with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=2) as ctx:
+            ctx.set_tuning("spin_timeout_ms", 100)
+            b = DeviceBatch(ctx, n, h, w, want_index=True)
+            b.disp.copy_(torch.from_numpy(np.stack(frames)))
             b.launch()
-        for r in range(4):
-            b.points.fill_(0)
-            b.index.fill_(0)
-            b.counts.fill_(0)
             torch.cuda.synchronize()
-            g.replay()
+            want = b.counts.cpu().numpy().copy()
+            if capture in ("torch", "torch_side"):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    b.launch()
+                # torch replays on its CURRENT stream: the legacy default stream, or a side stream
+                stream = torch.cuda.current_stream() if capture == "torch" else torch.cuda.Stream()
+                replay = g.replay
+            else:
+                raw = vp()
+                ck(hip.hipStreamCreateWithFlags(ctypes.byref(raw), 1), "hipStreamCreateWithFlags")  # non-blocking
+                stream = torch.cuda.ExternalStream(raw.value)
+                graph, gexec = vp(), vp()
+                ck(hip.hipStreamBeginCapture(raw, 0), "hipStreamBeginCapture")  # hipStreamCaptureModeGlobal
+                b.launch(stream=stream)
+                ck(hip.hipStreamEndCapture(raw, ctypes.byref(graph)), "hipStreamEndCapture")
+                ck(hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, ctypes.c_size_t(0)), "hipGraphInstantiate")
+
+                if capture == "hip_null":   # captured on `raw`, launched on the legacy default stream
+                    stream = torch.cuda.default_stream()
+
+                    def replay():
+                        ck(hip.hipGraphLaunch(gexec, None), "hipGraphLaunch")
+                else:
+                    def replay():
+                        ck(hip.hipGraphLaunch(gexec, raw), "hipGraphLaunch")
+            results = []
+            with torch.cuda.stream(stream):
+                for r in range(4):
+                    b.counts.fill_(0)   # stream-ordered with the replay
+                    replay()
+                    if host_reads:
+                        torch.cuda.synchronize()
+                        ok = np.array_equal(b.counts.cpu().numpy(), want)
+                        results.append(f"replay {r}: counts {'ok' if ok else 'WRONG'}, {flag(ctx)} {dirty(ctx)}")
             torch.cuda.synchronize()
-            got = b.counts.cpu().numpy()
-            try:
-                ctx.check_async_error()
-                flag = "clear"
-            except d2pc.D2pcError as e:
-                flag = "TIMEOUT FLAG SET"
-            print(f"{w}x{h} x{n} replay {r}: counts {'ok' if np.array_equal(got, want) else 'WRONG ' + str(got.tolist())}, {flag}", flush=True)
+            if not host_reads:
+                ok = np.array_equal(b.counts.cpu().numpy(), want)
+                results.append(f"after 4 replays without a host read: counts {'ok' if ok else 'WRONG'}, {flag(ctx)} {dirty(ctx)}")
+            print(f"capture via {capture:10s}, host reads between replays {host_reads}: " + "; ".join(results), flush=True)
