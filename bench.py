@@ -156,11 +156,13 @@ def timed_steps(batch, steps, warmup, dist_sync):
     return t1 - t0, e0.elapsed_time(e1) / steps
 
 
-def timed_rounds(batch, n, warmup=2, floor_ms=100.0, min_rounds=5, max_rounds=400):
+def timed_rounds(batch, n, warmup=2, floor_ms=100.0, min_rounds=5, max_rounds=400, heat_ms=30.0):
     """Side measurements and spreads: ROUNDS of `n` back-to-back launches, every round between two HIP events
     on the launch stream, as many rounds as it takes for the GPU time to sum to >= floor_ms (one short probe
     round sizes the run; then everything is enqueued with ONE synchronisation at the end, so no round starts
-    on an idle device).  Returns the per-round averages in ms per launch."""
+    on an idle device).  ~heat_ms of untimed launches come first: after seconds of idleness (frames generated on
+    the CPU) a kernel takes ~25 ms of back-to-back launches to reach its steady time (profiles/r03_warmup_ramp.txt).
+    Returns the per-round averages in ms per launch."""
     for _ in range(warmup):
         batch.launch()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -170,6 +172,8 @@ def timed_rounds(batch, n, warmup=2, floor_ms=100.0, min_rounds=5, max_rounds=40
     b.record()
     torch.cuda.synchronize()
     probe = max(a.elapsed_time(b), 1e-3)
+    for _ in range(int(min(2000, heat_ms / probe * n))):
+        batch.launch()
     rounds = int(min(max_rounds, max(min_rounds, -(-floor_ms // probe))))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(rounds + 1)]
     ev[0].record()
@@ -404,6 +408,11 @@ def main():
 
     batch = DeviceBatch(ctx, a.frames, H4K, W4K, want_index=False, device=dev)
     fill_batch(batch, rank, "uniform")
+    # Every rank first calibrates its device (>= 200 ms of plain fill / copy over the output buffer).  Besides the two
+    # rates this brings the device out of the idle state the CPU-side frame generation left it in: a kernel needs
+    # ~50 launches (~25 ms) after seconds of idleness to reach its steady time (profiles/r03_warmup_ramp.txt), more
+    # than the contract's W warm-up steps may be.
+    cal = device_calibration(ctx, batch)
     batch.launch()
     torch.cuda.synchronize()
     n_points = int(batch.counts.sum().item())
@@ -449,14 +458,17 @@ def main():
             "read_component_GBs": round(4 * a.frames * batch.roi_n / (kernel_ms * 1e-3) / 1e9, 1),
         },
     }
+    fills = multi_gpu.allgather_floats(cal["device_fill_GBs"])
+    if world > 1:
+        out["roofline"]["device_fill_GBs_per_rank"] = [round(x, 1) for x in fills]
+        out["roofline"]["device_copy_GBs_rank0"] = cal["device_copy_GBs"]
     if rank == 0 and world == 1:
         # after the contract's timed region: how much the same launch moves on this device (rounds of `steps`
-        # launches until >= 100 ms), and what the device gives a plain fill / copy in this very run
+        # launches until >= 100 ms), next to what the device gave a plain fill / copy before it
         sp = spread(timed_rounds(batch, a.steps, 0))
         out["roofline"]["kernel_ms_spread"] = sp
         out["roofline"]["frac_at_min_median_max_ms"] = [round(alg / (sp[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                         for k in ("min", "median", "max")]
-        cal = device_calibration(ctx, batch)
         out["roofline"].update(cal)
         out["roofline"]["achieved_over_device_fill"] = round(achieved / cal["device_fill_GBs"], 4)
         out["roofline"]["achieved_over_device_copy"] = round(achieved / cal["device_copy_GBs"], 4)
