@@ -13,6 +13,10 @@
 //        (stereoRectify's Q_ and the message's f, T, min_disparity) must not leak into each other
 //   d2pc_replay latency <in.raw> <w> <h> <mono8|mono16> <frames> [compact] [pinned]
 //        per-frame wall time of DisparityCb over <frames> calls (median, p10, p90 in microseconds)
+//   d2pc_replay --gpus N | --device D [...]
+//        the multi-GPU deployment in one process: RCCL broadcast of the calibration, one thread + context + frame
+//        queue per GPU, counters all-reduced (host/multi_gpu.hpp)
+// Every single-frame command takes device=<HIP ordinal> (default 0).
 // <in.raw> holds the sensor_msgs/Image data bytes (row-major, step = w*bpp).
 #include <algorithm>
 #include <chrono>
@@ -24,6 +28,7 @@
 #include <memory>
 
 #include "disparity_to_point_cloud_amd.hpp"
+#include "multi_gpu.hpp"
 #include "ros_shim.hpp"
 
 static std::vector<uint8_t> slurp(const char *path) {
@@ -49,6 +54,12 @@ static void write_cloud(const char *path, const Cloud &got) {
   o.write(reinterpret_cast<const char *>(got.data.data()), std::streamsize(got.data.size()));
 }
 
+static int device_from(int argc, char **argv) {
+  for (int i = 7; i < argc; ++i)
+    if (!strncmp(argv[i], "device=", 7)) return atoi(argv[i] + 7);
+  return 0;
+}
+
 static d2pc::ParamSource params_from(int argc, char **argv) {
   d2pc::ParamSource nh;  // d2pcloud.launch sets no params: defaults apply
   for (int i = 7; i < argc; ++i) {
@@ -64,7 +75,7 @@ static int run_node(int argc, char **argv, const char *out_path, Fn call) {
   typename M::PointCloud2 got;
   int published = 0;
   d2pc::Disparity2PCloudT<M> node(
-      params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { got = pc; ++published; }, 0, nullptr,
+      params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { got = pc; ++published; }, device_from(argc, argv), nullptr,
       has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false, !has_flag(argc, argv, "hostmedian"));
   call(node);
   if (published != 1) { fprintf(stderr, "nothing published\n"); return 3; }
@@ -76,7 +87,7 @@ template <class M>
 static int run_latency(int argc, char **argv, const std::shared_ptr<d2pc_shim::Image> &img, int frames) {
   size_t last = 0;
   d2pc::Disparity2PCloudT<M> node(
-      params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { last = pc.data.size(); }, 0, nullptr,
+      params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { last = pc.data.size(); }, device_from(argc, argv), nullptr,
       has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false, true);
   for (int i = 0; i < 20; ++i) node.DisparityCb(img);
   std::vector<double> us;
@@ -93,6 +104,10 @@ static int run_latency(int argc, char **argv, const std::shared_ptr<d2pc_shim::I
 }
 
 int main(int argc, char **argv) {
+  {
+    const d2pc_multi::Options mo = d2pc_multi::parse(argc, argv);
+    if (mo.gpus > 0 || !mo.error.empty()) return d2pc_multi::run(mo);
+  }
   if (argc < 7) { fprintf(stderr, "usage: see replay_main.cpp\n"); return 2; }
   const std::string cmd = argv[1], enc = argv[5];
   auto img = std::make_shared<d2pc_shim::Image>();
@@ -154,7 +169,7 @@ int main(int argc, char **argv) {
         typedef decltype(tag) M;
         std::vector<typename M::PointCloud2> got;
         d2pc::Disparity2PCloudT<M> node(
-            params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { got.push_back(pc); }, 0, nullptr,
+            params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { got.push_back(pc); }, device_from(argc, argv), nullptr,
             has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false, true);
         node.DisparityImageCb(dm);
         node.DisparityCb(img);

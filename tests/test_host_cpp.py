@@ -261,3 +261,86 @@ def test_pinned_allocator_logic_on_the_cpu(tmp_path):
                     "-fno-omit-frame-pointer", "-o", str(exe), src], check=True, capture_output=True, timeout=180)
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert p.returncode == 0 and "pinned allocator ok" in p.stdout, p.stdout + p.stderr
+
+
+# ------------------------------------------------- native multi-GPU mode of the harness (host/multi_gpu.hpp)
+def test_multi_gpu_mode_argument_handling(replay):
+    """`d2pc_replay --gpus N ...`: bad command lines are refused (exit 2) before anything touches a GPU or RCCL;
+    asking for more devices than the node has is exit 5 (no GPU here: every request is too many)."""
+    def run(*args):
+        p = subprocess.run([replay, *args], capture_output=True, text=True, timeout=60)
+        return p.returncode, p.stderr
+
+    for args, needle in ((("--gpus", "0"), "1..64"), (("--gpus", "two"), "1..64"), (("--gpus",), "1..64"),
+                         (("--gpus", "2", "--device", "1"), "ONE GPU"), (("--devices", "0,0"), "listed twice"),
+                         (("--gpus", "3", "--devices", "0,1"), "another number"), (("--gpus", "1", "--frames", "0"), "frame count"),
+                         (("--device", "0", "--median", "4"), "odd size"), (("--device", "0", "--encoding", "rgb8"), "mono8 or mono16"),
+                         (("--device", "0", "--depth", "9"), "1..8"), (("--device", "0", "--bogus"), "unknown argument"),
+                         (("--gpus", "1", "focal=3"), "unknown parameter")):
+        rc, err = run(*args)
+        assert rc == 2 and needle in err, (args, rc, err)
+    import disparity_to_point_cloud_amd as d2pc
+    if d2pc.device_count() == 0:
+        rc, err = run("--gpus", "2")
+        assert rc == 5 and "no CPU path" in err
+    # the single-frame commands are untouched by the new parser
+    rc, err = run()
+    assert rc == 2 and "usage" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["parity", "compact"])
+@pytest.mark.parametrize("how", ["--gpus", "--device"])
+def test_multi_gpu_mode_with_one_rank(replay, tmp_path, mode, how):
+    """The C++ multi-GPU deployment with N = 1 (all a one-GPU box allows): ncclCommInitAll over one device, the
+    136-byte blob through ncclBroadcast (bitwise what rank 0 packed), a context configured from the RECEIVED bytes,
+    the rank's frame queue, counters through ncclAllReduce; the last cloud against the oracle."""
+    import json
+
+    import disparity_to_point_cloud_amd as d2pc
+
+    rng = np.random.default_rng(41)
+    img = rng.integers(0, 256, size=(480, 752)).astype(np.uint8)
+    img[rng.random(img.shape) < 0.3] = 0
+    src = tmp_path / "frame.raw"
+    src.write_bytes(img.tobytes())
+    prefix = tmp_path / "multi"
+    args = [replay, how, "1" if how == "--gpus" else "0", "--frames", "7", "--in", str(src), "--out", str(prefix),
+            "fx_=700.5", "base_line_=0.11"]
+    if mode == "compact":
+        args.append("--compact")
+    p = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    q = d2pc.make_q_flavour(fx=700.5, baseline=0.11)
+    want_blob = d2pc.calib_pack(q, 40, d2pc.MODE_COMPACT if mode == "compact" else d2pc.MODE_PARITY)
+    assert (tmp_path / "multi.rank0.blob").read_bytes() == want_blob
+    med = oracle.median_u8(img, 11)
+    if mode == "parity":
+        want = oracle.reproject(med, q, border=40, scale=0.125)
+    else:
+        want, _ = oracle.reproject_compact(med, q, border=40, scale=0.125)
+    pts = np.frombuffer((tmp_path / "multi.rank0.cloud").read_bytes(), dtype=np.float32).reshape(-1, 4)
+    assert_points_close(pts, want, max_ulp=1, rel=1e-5, what="multi-GPU mode, rank 0")
+    assert rec["n_gpus"] == 1 and rec["devices"] == [0] and rec["frames"] == 7 and rec["per_rank_frames"] == [7]
+    assert rec["pixels"] == 7 * 752 * 480 and rec["points"] == 7 * len(want)
+
+
+@pytest.mark.gpu
+def test_multi_gpu_mode_refuses_a_second_device_on_a_one_gpu_box(replay):
+    import disparity_to_point_cloud_amd as d2pc
+    if d2pc.device_count() != 1:
+        pytest.skip("needs exactly one GPU")
+    p = subprocess.run([replay, "--gpus", "2"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 5 and "exposes 1 HIP device" in p.stderr
+
+
+@pytest.mark.gpu
+def test_multi_gpu_mode_synthetic_mono16_stream(replay):
+    """The seeded synthetic stream (no input file), mono16 frames, compact clouds: runs, counts add up."""
+    import json
+    p = subprocess.run([replay, "--gpus", "1", "--frames", "9", "--encoding", "mono16", "--compact", "--width", "640",
+                        "--height", "480", "--depth", "2"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["frames"] == 9 and rec["pixels"] == 9 * 640 * 480 and 0 < rec["points"] <= 9 * 560 * 400
