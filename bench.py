@@ -585,6 +585,47 @@ def main():
             "achieved_GBs": round(ab / (kms * 1e-3) / 1e9, 1), "frac": round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "kernel_ms_avg": kms, "kernel_ms_spread": sp,
             "what": "fused cpp:61 decode: 1 B read + 16 B written per pixel"}
+        # the same callback body with a DENSE cloud out (COMPACT): 8-bit frames with ~30 % zero pixels (no match),
+        # in 64 x 64 blocks and iid (the 11 x 11 median closes most iid holes) -- one kernel
+        # (k_callback_bs_compact) against the filter launch + the single-pass compaction launch
+        c4 = d2pc.Context(device_id=local_rank, border=a.border, mode=d2pc.MODE_COMPACT, q=q)
+        b4 = DeviceBatch(c4, a.frames, H4K, W4K, dtype=torch.uint8, want_index=True, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(0xD2D)
+        for hole_kind in ("blocky", "iid"):
+            raw4 = raw.clone()
+            if hole_kind == "blocky":
+                m = torch.rand((a.frames, (H4K + 63) // 64, (W4K + 63) // 64), device=dev, generator=gen) < 0.3
+                raw4[m.repeat_interleave(64, dim=1).repeat_interleave(64, dim=2)[:, :H4K, :W4K]] = 0
+            else:
+                raw4[torch.rand(raw4.shape, device=dev, generator=gen) < 0.3] = 0
+
+            class _BodyCompact:
+                def launch(self):
+                    c4.process_mono_device(raw4.data_ptr(), d2pc.DTYPE_U8, W4K, H4K, W4K, W4K * H4K, a.frames, 11, 0.125,
+                                           b4.points.data_ptr(), b4.index.data_ptr(), b4.stride, b4.counts.data_ptr(), s3)
+
+            rec = {}
+            for fused in (1, 0):
+                c4.set_tuning("callback_fused_compact", fused)
+                _BodyCompact().launch()
+                torch.cuda.synchronize()
+                c4.compact_stats_reset()
+                sp = spread(timed_rounds(_BodyCompact(), n_side, 3))
+                c4.check_async_error()
+                rec[fused] = (sp, compaction_counters(c4))
+            npts = int(b4.counts.sum().item())
+            kms, kms2 = rec[1][0]["median"], rec[0][0]["median"]
+            variants[f"callback_u8_median11_compact_30pct_zero_{hole_kind}"] = {
+                "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
+                "kernel_ms_spread": rec[1][0], "points_per_step": npts, "compaction_counters": rec[1][1],
+                "what": "d2pc_process_mono_device, COMPACT + indices: k_callback_bs_compact<11> (median of a tile, its "
+                        "surviving points in row-major order, row counts handed over inside the launch)",
+                "as_two_launches_ms": kms2, "as_two_launches_ms_spread": rec[0][0],
+                "as_two_launches_what": "k_median_bs_u8<11> over the inset ROI + k_compact_onepass<U8>",
+                "speedup_over_two_launches": round(kms2 / kms, 3)}
+            del raw4
+        del b4
+        c4.close()
         del b3
         c3.close()
         if not a.no_host_path:

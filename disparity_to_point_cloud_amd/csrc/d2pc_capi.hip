@@ -103,6 +103,7 @@ struct d2pc_ctx {
   CompactStats *d_stats = nullptr;  // single-pass counters, added to by the launches' blocks (d2pc_compact_stats)
   int membench_blocks_per_cu = 8;
   // d2pc_process_mono_device: two internal streams + scratch for the filtered frames
+  int cb_fused_compact = 1;      // ... and the COMPACT form of that kernel (k_callback_bs_compact); 0 = two launches in COMPACT mode
   int cb_fused = 1;              // d2pc_process_mono_device, PARITY: median + points in one kernel, tile by tile (k_callback_bs:
                                  // bit-sliced median, the tile's points from LDS) when the launch is large enough for the
                                  // bit-sliced filter; 0 = always the filter launch followed by the reprojection launch
@@ -354,6 +355,8 @@ int acquire_buf(d2pc_ctx *ctx, BufPool &pool, hipStream_t stream, size_t need, s
 int reserve_buf(d2pc_ctx *ctx, BufPool &pool, size_t need, size_t need2) {
   if (need > pool.reserve) pool.reserve = need;
   if (need2 > pool.reserve2) pool.reserve2 = need2;
+  need = pool.reserve;
+  need2 = pool.reserve2;
   StateBuf *pick = nullptr;
   for (StateBuf *b : pool.bufs)
     if (!b->captured && state_idle(*b) && b->cap >= need && b->cap2 >= need2) return D2PC_OK;
@@ -380,6 +383,16 @@ void free_pool(BufPool &pool) {
   pool.bufs.clear();
 }
 
+// bound on |u + cx|, |v + cy|, |f| over the frame, scaled by 2^-126: any |W| at least this large keeps every
+// quotient below 2^126 < FLT_MAX (QStereo::w_safe: the exact validity predicate of the COMPACT kernels)
+double w_safe_for(const d2pc_ctx *ctx, const Geom &g) {
+  const double height = double((g.last_off / (g.row_stride ? g.row_stride : 1u)) + 1u);
+  const double mx = std::fmax(std::fabs(ctx->qs.cx), std::fabs(ctx->qs.cx + double(g.width)));
+  const double my = std::fmax(std::fabs(ctx->qs.cy), std::fabs(ctx->qs.cy + height));
+  const double m = std::fmax(std::fabs(ctx->qs.f), std::fmax(mx, my));
+  return std::isfinite(m) ? std::ldexp(m, -126) : std::numeric_limits<double>::infinity();
+}
+
 int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d_out, uint32_t *d_idx,
             uint32_t *d_counts, hipStream_t stream, StateBuf *fixed_state = nullptr, int force_algo = 0) {
   LaunchArgs a;
@@ -397,15 +410,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   // row at a 16-B aligned address
   a.vec_rows = !ctx->no_vec_rows && dtype == D2PC_DTYPE_F32 && g.roi_w % 4 == 0 && g.border % 4 == 0 &&
                g.row_stride % 16 == 0 && g.in_frame_stride % 16 == 0 && reinterpret_cast<uintptr_t>(d_disp) % 16 == 0;
-  {
-    // bound on |u + cx|, |v + cy|, |f| over the frame, scaled by 2^-126: any
-    // |W| at least this large keeps every quotient below 2^126 < FLT_MAX
-    const double height = double((g.last_off / (g.row_stride ? g.row_stride : 1u)) + 1u);
-    const double mx = std::fmax(std::fabs(ctx->qs.cx), std::fabs(ctx->qs.cx + double(g.width)));
-    const double my = std::fmax(std::fabs(ctx->qs.cy), std::fabs(ctx->qs.cy + height));
-    const double m = std::fmax(std::fabs(ctx->qs.f), std::fmax(mx, my));
-    a.qs.w_safe = std::isfinite(m) ? std::ldexp(m, -126) : std::numeric_limits<double>::infinity();
-  }
+  a.qs.w_safe = w_safe_for(ctx, g);
   // grid: many more blocks than fit (the dispatcher keeps the CUs fed as blocks
   // retire), each walking a few tiles: min(T, max(CUs*blocks_per_cu, T/4))
   uint32_t want = uint32_t(ctx->cu_count) * uint32_t(ctx->blocks_per_cu);
@@ -817,6 +822,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "callback_chunks") && value >= 0 && value <= 64) ctx->cb_chunks = value;
   else if (!strcmp(key, "callback_fused") && (value == 0 || value == 1)) ctx->cb_fused = value;
+  else if (!strcmp(key, "callback_fused_compact") && (value == 0 || value == 1)) ctx->cb_fused_compact = value;
   else if (!strcmp(key, "host_direct_read") && (value == 0 || value == 1)) ctx->host_direct_read = value;
   else if (!strcmp(key, "median_algo") && value >= 0 && value <= 2) ctx->median_algo = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
@@ -847,7 +853,14 @@ int d2pc_reserve_mono(d2pc_ctx *ctx, int dtype, int width, int height, int n_fra
   const size_t bytes = ((size_t(width) + 255) & ~size_t(255)) * size_t(height) * size_t(n_frames);
   int st = reserve_buf(ctx, ctx->cb_scratch, bytes, dtype == D2PC_DTYPE_MONO16 ? bytes : 0);
   if (st != D2PC_OK) return st;
-  return ctx->cfg.mode == D2PC_MODE_COMPACT ? d2pc_reserve(ctx, width, height, n_frames) : D2PC_OK;
+  if (ctx->cfg.mode != D2PC_MODE_COMPACT) return D2PC_OK;
+  // COMPACT: the state of the two-launch form's compaction and of the tile-fused kernel, whichever is larger
+  const long long b = ctx->cfg.border, rw = (long long)width - 2 * b, rh = (long long)height - 2 * b;
+  if (rw > 0 && rh > 0 && (rw + 255) / 256 <= (long long)kCbMaxTilesX) {
+    const size_t cb = callback_compact_state_bytes(uint32_t((rw + 255) / 256), uint32_t((rh + 31) / 32), uint32_t(n_frames), nullptr);
+    if (cb > ctx->states.reserve) ctx->states.reserve = cb;
+  }
+  return d2pc_reserve(ctx, width, height, n_frames);
 }
 
 int d2pc_release_graph_buffers(d2pc_ctx *ctx) {
@@ -1265,11 +1278,11 @@ int callback_event(d2pc_ctx *ctx, size_t i, hipEvent_t *e) {
   return D2PC_OK;
 }
 
-// Can the tile-fused kernel (median + points per tile) serve this call?
+// Can the tile-fused kernel (median + points per tile) serve this call?  COMPACT: a band of tiles must fit the
+// blocks resident at once (k_callback_bs_compact's hand-off), i.e. ROIs up to 128 x 256 pixels wide.
 bool callback_one_kernel_ok(const d2pc_ctx *ctx, bool compact, const Geom &g) {
-  (void)ctx;
-  (void)g;
-  return !compact;
+  if (!compact) return true;
+  return ctx->cb_fused_compact == 1 && (g.roi_w + 255u) / 256u <= kCbMaxTilesX;
 }
 
 }  // namespace
@@ -1391,10 +1404,28 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
         a.counts = d_counts ? d_counts + f0 : nullptr;
         a.dtype = D2PC_DTYPE_U8;
         a.stream = sr;
-        a.geom = g;
         memcpy(a.q.q, ctx->q, sizeof a.q.q);
         a.qs = ctx->qs;
+        a.qs.w_safe = w_safe_for(ctx, g);
         a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
+        if (compact) {  // the COMPACT form hands row counts over between the tiles of a band: its own state
+          uint32_t stride = 0;
+          a.state_bytes = callback_compact_state_bytes((g.roi_w + 255u) / 256u, (g.roi_n / g.roi_w + 31u) / 32u, uint32_t(nf), &stride);
+          g.frame_state_stride = stride;
+          a.stats = ctx->d_stats;
+          StateBuf *sb = nullptr;
+          if ((st = acquire_buf(ctx, ctx->states, sr, a.state_bytes, 0, nullptr, &sb)) != D2PC_OK) return st;
+          a.state = sb->p;
+          sb->algo = 2;  // its header carries the hand-off's timeout flag, like the single pass's
+          a.geom = g;
+          D2PC_HIP(ctx, launch_callback_bs_compact(a, m, kin, median_ksize));
+          if (!sb->captured) {
+            D2PC_HIP(ctx, hipEventRecord(sb->done, sr));
+            sb->pending = true;
+          }
+          continue;
+        }
+        a.geom = g;
         D2PC_HIP(ctx, launch_callback_bs(a, m, kin, median_ksize));
         continue;
       }

@@ -108,6 +108,11 @@ struct CompactStats {
   } slot[kStatSlots];
   unsigned long long launches, timeouts, dbg[2];
 };
+// tile-fused COMPACT callback kernel (k_callback_bs_compact): per frame [ticket, 128 B][band accumulators, 8 B
+// each, rounded up to 128 B][64 B of row counts per tile]
+constexpr uint32_t kCbTicketBytes = 128;
+constexpr uint32_t kCbMaxTilesX = 128;  // tiles per band: far below the blocks resident at once (3 per CU)
+__host__ __device__ inline uint32_t cb_band_acc_bytes(uint32_t tiles_y) { return (tiles_y * 8u + 127u) & ~127u; }
 constexpr uint32_t kFrameTicketBytes = 256;   // the ticket word has a 256-B block to itself
 constexpr uint32_t kGroupAccStride = 128;     // one group accumulator per 128-B line
 constexpr uint64_t kGranuleTag = uint64_t(1) << 63;

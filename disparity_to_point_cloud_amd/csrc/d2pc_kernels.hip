@@ -1185,6 +1185,265 @@ __global__ __launch_bounds__(kBlock + 64) void k_compact_onepass(const uint8_t *
 }
 
 // --------------------------------------------------------------------------
+// K1c: the callback body TILE BY TILE in COMPACT mode -- bit-sliced median of a 256 x 32 tile, then the tile's
+// SURVIVING points, in the CPU loop's row-major order (cpp:70-76 + the north-star's validity compaction), in one
+// kernel.  The two-launch form (filter launch, filtered frames through memory, compaction launch) stays as the
+// fallback and as the device-side oracle.
+//
+// Order.  A tile holds 32 rows of 256 columns; in the output, row y of tile (band ty, column tx) follows row y of
+// the tile to its left and precedes row y of the tile to its right, so the position of the first survivor of a row is
+//     S(ty)                     survivors of all bands above            (band accumulators, counted like the
+//                                                                        single pass's group accumulators)
+//   + sum of the band's rows above y over ALL its tiles                  (the 32 row counts every tile of the
+//   + sum of row y over the band's tiles to the left                      band publishes: 64 bytes per tile)
+// A tile therefore needs every tile of ITS BAND (left and right) and the totals of all bands above.
+//
+// Hand-off.  Tiles are handed out by a per-frame ticket, band by band, left to right (a block serves frame
+// blockIdx % n_frames; exactly tiles_per_frame blocks per frame), so the tiles of a band hold consecutive tickets.
+// A block publishes its row counts as soon as the filter is done -- sixteen tagged dwords (the data is the flag:
+// two 9-bit counts and a tag bit each, one sc1 store instruction, nothing to drain) plus ONE agent-scope add of
+// {1, tile total} to the band's accumulator -- and waits until every tile of its band has published and all bands
+// above are complete; the two kinds of words are polled in the same pass, so a wait that finds everything ready
+// costs one memory round trip.  No
+// deadlock at any residency >= tiles_x blocks (the host refuses wider frames): every ticket below the highest one
+// issued is held by a running block; a band whose tickets are all issued completes because its tiles wait only for
+// bands that are all issued (induction from band 0); the blocks that retire then take the remaining tickets of
+// the one band that may be partly issued.  Waits are bounded by time like the single pass's (sticky flag,
+// 0xFFFFFFFF in d_counts).
+// --------------------------------------------------------------------------
+constexpr uint32_t kCbRowTag = 1u << 31;
+struct CbCompactState {
+  uint32_t *ticket;
+  uint64_t *band_acc;  // (tiles arrived << 32) | survivors, one per band, packed
+  uint32_t *row_cnt;   // [tile][16]: dword p = kCbRowTag | survivors of the tile's rows 2p | 2p+1 << 9 (a count is <= 256)
+  __device__ __forceinline__ CbCompactState(uint8_t *state, const Geom &g, uint32_t f, uint32_t tiles_y) {
+    uint8_t *fs = state + sizeof(StateHeader) + uint64_t(f) * g.frame_state_stride;
+    ticket = reinterpret_cast<uint32_t *>(fs);
+    band_acc = reinterpret_cast<uint64_t *>(fs + kCbTicketBytes);
+    row_cnt = reinterpret_cast<uint32_t *>(fs + kCbTicketBytes + cb_band_acc_bytes(tiles_y));
+  }
+};
+
+template <int KS, int QK>
+__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_callback_bs_compact(
+    const uint8_t *__restrict__ src, float4 *__restrict__ out, uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
+    uint8_t *state, const MedianArgs ma, const Geom g, const QArg<QK> Q) {
+  using S = MedianBsShape<KS>;
+  using gu32 = __attribute__((address_space(1))) uint32_t;
+  using gu64 = __attribute__((address_space(1))) uint64_t;
+  static_assert(S::THREADS == 256 && S::TH == 32, "one thread per byte value fills the table; 32 row counts per tile");
+  __shared__ __attribute__((aligned(16))) uint32_t s_w[S::W_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_raw[S::RAW_WORDS];
+  __shared__ uint32_t s_tile, s_exact;
+  __shared__ uint32_t s_cnt[32], s_base[32];
+  __shared__ uint32_t s_stat[3];
+  // per byte value: 1/W, Z and the validity class of the point (0 dropped, 1 kept, 2 = only the arithmetic can tell).
+  // Tables of their own (not in the staged rows' space as in k_callback_bs): they are filled while the ticket's
+  // atomic is in flight
+  __shared__ double lut_iw[256];
+  __shared__ float lut_z[256];
+  __shared__ uint8_t lut_cls[256];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
+  const uint32_t f = blockIdx.x % g.n_frames;  // the grid is tiles_per_frame * n_frames: every frame gets its tiles' worth of blocks
+  const CbCompactState cs(state, g, f, ma.tiles_y);
+  uint32_t tk = 0;
+  if (tid == 0) {
+    tk = atomicAdd(cs.ticket, 1u);  // its round trip (2-3 us under load) runs under the table's divisions
+    s_exact = QK != QK_STEREO ? 1u : 0u;
+  }
+  if (tid < 3) s_stat[tid] = 0;
+  if constexpr (QK == QK_STEREO) {
+    const float d = __fmul_rn(float(tid), g.scale);  // cpp:61, as load_disparity<DT_U8>
+    const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
+    const double nw = fma(Q.s.a, double(dsel), Q.s.b);
+    const double iw = 1.0 / nw;
+    lut_iw[tid] = iw;
+    lut_z[tid] = big_z_rule(d, float(Q.s.f * iw));
+    // the single pass's predicate (tile_count): finite, non-zero W of at least w_safe => every coordinate finite
+    const bool fin = finite_nonzero(nw), big = fabs(nw) >= Q.s.w_safe, keep = !(d <= g.min_disparity);
+    const uint32_t cls = fin && keep ? (big ? 1u : 2u) : 0u;
+    lut_cls[tid] = uint8_t(cls);
+    __syncthreads();                  // (s_exact's initial value is in place)
+    if (cls == 2u) s_exact = 1u;      // (benign race: every writer stores 1)
+  }
+  if (tid == 0) s_tile = tk;
+  __syncthreads();
+  const uint32_t lt = s_tile;  // < tiles_x * tiles_y: as many tickets as blocks
+  const uint32_t ty = lt / ma.tiles_x, tx = lt - ty * ma.tiles_x;
+  const uint32_t x0 = ma.out_x0 + tx * uint32_t(S::TW), y0 = ma.out_y0 + ty * uint32_t(S::TH);
+  median_bs_tile<KS>(src + uint64_t(f) * ma.src_frame_stride, ma, int(x0), int(y0), s_w, s_raw, tid);
+  const bool exact = s_exact != 0;  // block-uniform: both phases below decide every pixel the same way
+
+  const uint8_t *ob = reinterpret_cast<const uint8_t *>(s_w);
+  const uint32_t x_end = ma.out_x0 + ma.out_w, y_end = ma.out_y0 + ma.out_h;
+  double xs[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    xs[q] = 0.0;
+    if constexpr (QK == QK_STEREO) xs[q] = double(x0 + 64u * uint32_t(q) + lane) + Q.s.cx;
+  }
+  // one pixel: its point (when wanted) and whether it survives
+  auto pixel = [&](uint32_t x, uint32_t y, uint32_t raw, int q, double ys, bool want_point, float &X, float &Y, float &Z) -> bool {
+    if constexpr (QK == QK_STEREO) {
+      if (!exact && !want_point) return lut_cls[raw] == 1u;
+      const double iw = lut_iw[raw];
+      X = float(xs[q] * iw);
+      Y = float(ys * iw);
+      Z = lut_z[raw];
+      if (!exact) return lut_cls[raw] == 1u;
+      return point_is_valid(X, Y, Z, __fmul_rn(float(raw), g.scale), g.min_disparity);
+    } else {
+      const float d = __fmul_rn(float(raw), g.scale);
+      reproject(Q, x, y, d, X, Y, Z);
+      return point_is_valid(X, Y, Z, d, g.min_disparity);
+    }
+  };
+
+  // ---- count: survivors per row of the tile (a wave takes every fourth row, 64 columns per step) ----------
+#pragma unroll 1
+  for (uint32_t r = wave; r < uint32_t(S::TH); r += uint32_t(S::THREADS / 64)) {
+    const uint32_t y = y0 + r;
+    uint32_t cnt = 0;
+    if (y < y_end) {
+      double ys = 0.0;
+      if constexpr (QK == QK_STEREO) ys = double(y) + Q.s.cy;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t x = x0 + 64u * uint32_t(q) + lane;
+        const uint32_t raw = ob[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
+        float X, Y, Z;
+        const bool ok = pixel(x, y, raw, q, ys, false, X, Y, Z) && x < x_end;
+        cnt += uint32_t(__popcll(__ballot(ok)));
+      }
+    }
+    if (lane == 0) s_cnt[r] = cnt;
+  }
+  __syncthreads();
+
+  // ---- hand-off (wave 0): publish the 32 row counts, wait for the band and the bands above, place the rows ----
+  if (wave == 0) {
+    const uint32_t mine = lane < 32u ? s_cnt[lane] : 0u;
+    const uint32_t tile_total = wave_sum(mine);
+    if (lane < 16u)
+      __hip_atomic_store((gu32 *)(cs.row_cnt + lt * 16u + lane), kCbRowTag | s_cnt[2u * lane] | (s_cnt[2u * lane + 1u] << 9),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0)
+      __hip_atomic_fetch_add((gu64 *)(cs.band_acc + ty), (uint64_t(1) << 32) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // One pass = the accumulators of the bands above (64 per step) and the band's row-count words (lane = (j, p):
+    // tiles j, j + 4, ..., row pair p), all requested together; a pass in which every word is complete ends the wait.
+    const uint32_t j = lane >> 4, p = lane & 15u;
+    uint32_t above = 0, t0 = 0, t1 = 0, l0 = 0, l1 = 0, spins = 0;
+    uint64_t w0 = 0;
+    for (;;) {
+      bool ok = true;
+      above = 0;
+      for (uint32_t b0 = 0; b0 < ty; b0 += 64u) {
+        const uint32_t bi = b0 + lane;
+        if (bi < ty) {
+          const uint64_t v = __hip_atomic_load((gu64 *)(cs.band_acc + bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && uint32_t(v >> 32) == ma.tiles_x;
+          above += uint32_t(v);
+        }
+      }
+      t0 = t1 = l0 = l1 = 0;
+      for (uint32_t k = j; k < ma.tiles_x; k += 4u) {
+        const uint32_t v = __hip_atomic_load((gu32 *)(cs.row_cnt + (ty * ma.tiles_x + k) * 16u + p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (v & kCbRowTag) != 0u;
+        const uint32_t c0 = v & 0x1ffu, c1 = (v >> 9) & 0x1ffu;
+        t0 += c0, t1 += c1;
+        if (k < tx) l0 += c0, l1 += c1;
+      }
+      if (__all(ok)) break;
+      if (spins == 0) w0 = __builtin_amdgcn_s_memrealtime();
+      backoff(spins);
+      ++spins;
+      // bounded by time, and over as soon as ANY wave of the launch has given up (sticky flag)
+      if ((spins & 7u) == 0 && (__builtin_amdgcn_s_memrealtime() - w0 > uint64_t(g.spin_ticks) ||
+                                __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (lane == 0 && __hip_atomic_exchange(&hdr->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+          atomicAdd(&hdr->stats->timeouts, 1ull);
+        break;
+      }
+    }
+#if D2PC_ONEPASS_STATS
+    if (spins && lane == 0) {
+      s_stat[1] = spins;
+      s_stat[2] = uint32_t(__builtin_amdgcn_s_memrealtime() - w0);
+    }
+#endif
+    above = wave_sum(above);
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      t0 += __shfl_xor(t0, o, 64), t1 += __shfl_xor(t1, o, 64);
+      l0 += __shfl_xor(l0, o, 64), l1 += __shfl_xor(l1, o, 64);
+    }
+    // lanes 0..15 hold the row pairs; spread to one row per lane: row r = 2p + h comes from lane p
+    const uint32_t src_lane = (lane & 31u) >> 1;
+    const uint32_t tt0 = __shfl(t0, src_lane, 64), tt1 = __shfl(t1, src_lane, 64);
+    const uint32_t ll0 = __shfl(l0, src_lane, 64), ll1 = __shfl(l1, src_lane, 64);
+    const uint32_t row_total = lane < 32u ? ((lane & 1u) ? tt1 : tt0) : 0u;
+    const uint32_t row_left = (lane & 1u) ? ll1 : ll0;
+    uint32_t incl = row_total;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const uint32_t n = __shfl_up(incl, o, 64);
+      if (lane >= uint32_t(o)) incl += n;
+    }
+    if (lane < 32u) s_base[lane] = above + incl - row_total + row_left;
+    const uint32_t band_total = __builtin_amdgcn_readlane(incl, 31);
+    if (counts && ty == ma.tiles_y - 1u && tx == 0u && lane == 0u) {
+      const bool bad = __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      __hip_atomic_store(counts + f, bad ? kCountTimedOut : above + band_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+
+  // ---- scatter: the same decisions, the points, their ordered stores ------------------------------------
+  float4 *fout = out + uint64_t(f) * g.out_frame_stride;
+  uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
+#pragma unroll 1
+  for (uint32_t r = wave; r < uint32_t(S::TH); r += uint32_t(S::THREADS / 64)) {
+    const uint32_t y = y0 + r;
+    if (y >= y_end) break;
+    uint32_t row_pos = s_base[r];
+    double ys = 0.0;
+    if constexpr (QK == QK_STEREO) ys = double(y) + Q.s.cy;
+    uint32_t raw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[q] = ob[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t x = x0 + 64u * uint32_t(q) + lane;
+      float X, Y, Z;
+      const bool ok = pixel(x, y, raw[q], q, ys, true, X, Y, Z) && x < x_end;
+      const uint64_t m = __ballot(ok);
+      const uint32_t pos = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), row_pos));
+      // pos < roi_n always holds for a correct prefix; the guard keeps a timed-out prefix from becoming an out-of-bounds store
+      if (ok && pos < g.roi_n) {
+        store_point<D2PC_ONEPASS_STORE_NT != 0>(fout, pos, X, Y, Z);
+        if (fidx) store_index(fidx, pos, y * g.width + x);
+      }
+      row_pos += uint32_t(__popcll(m));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // a block that saw the launch break marks its frame, whether or not the frame's last tile has reported already
+    if (counts && __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      __hip_atomic_store(counts + f, kCountTimedOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if D2PC_ONEPASS_STATS
+    CompactStats::Slot *sl = hdr->stats->slot + (blockIdx.x % uint32_t(kStatSlots));
+    atomicAdd(&sl->tiles, 1ull);
+    if (s_stat[1]) {
+      atomicAdd(&sl->failed_polls, (unsigned long long)s_stat[1]);
+      atomicAdd(&sl->wait_ticks, (unsigned long long)s_stat[2]);
+    }
+#endif
+  }
+}
+
+// --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
 template <int QK>
@@ -1347,6 +1606,54 @@ hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src
     default: return hipErrorInvalidValue;
   }
 #undef D2PC_CB_BS
+  return hipGetLastError();
+}
+
+size_t callback_compact_state_bytes(uint32_t tiles_x, uint32_t tiles_y, uint32_t n_frames, uint32_t *frame_stride) {
+  const uint64_t b = uint64_t(kCbTicketBytes) + cb_band_acc_bytes(tiles_y) + uint64_t(tiles_x) * tiles_y * 64u;
+  const uint32_t stride = uint32_t((b + 255) & ~uint64_t(255));
+  if (frame_stride) *frame_stride = stride;
+  return sizeof(StateHeader) + size_t(n_frames) * stride;
+}
+
+hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const void *src, int ksize) {
+  if (!median_ksize_supported(ksize) || m.out_w == 0 || m.out_h == 0 || !a.state || !a.stats || !a.counts) return hipErrorInvalidValue;
+  if (m.out_x0 != a.geom.border || m.out_y0 != a.geom.border || m.out_w != a.geom.roi_w ||
+      uint64_t(m.out_w) * m.out_h != a.geom.roi_n)
+    return hipErrorInvalidValue;  // the filter's output rectangle must be the reprojection's ROI
+  using S = MedianBsShape<11>;  // the tile shape does not depend on k
+  m.tiles_x = (m.out_w + S::TW - 1) / S::TW;
+  m.tiles_y = (m.out_h + S::TH - 1) / S::TH;
+  if (m.tiles_x > kCbMaxTilesX) return hipErrorInvalidValue;  // a band must fit the resident blocks (see the kernel)
+  const uint64_t blocks = uint64_t(m.tiles_x) * m.tiles_y * m.n_frames;
+  if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  uint32_t stride = 0;
+  if (callback_compact_state_bytes(m.tiles_x, m.tiles_y, m.n_frames, &stride) != a.state_bytes || stride != a.geom.frame_state_stride ||
+      a.geom.n_frames != m.n_frames)
+    return hipErrorInvalidValue;
+  const uint32_t n16 = uint32_t((a.state_bytes + 15) / 16);
+  hipLaunchKernelGGL(k_state_clear, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(a.state), n16,
+                     static_cast<CompactStats *>(a.stats));
+  const uint8_t *s8 = static_cast<const uint8_t *>(src);
+  float4 *o = static_cast<float4 *>(a.out_points);
+  uint8_t *state = static_cast<uint8_t *>(a.state);
+#define D2PC_CB_BSC(KS, QK)                                                                                                  \
+  hipLaunchKernelGGL((k_callback_bs_compact<KS, QK>), dim3(uint32_t(blocks)), dim3(S::THREADS), 0, a.stream, s8, o, a.out_index, \
+                     a.counts, state, m, a.geom, make_qarg<QK>(a))
+  switch (ksize * 2 + (a.q_kind == QK_STEREO ? 1 : 0)) {
+    case 6: D2PC_CB_BSC(3, QK_GENERAL); break;
+    case 7: D2PC_CB_BSC(3, QK_STEREO); break;
+    case 10: D2PC_CB_BSC(5, QK_GENERAL); break;
+    case 11: D2PC_CB_BSC(5, QK_STEREO); break;
+    case 14: D2PC_CB_BSC(7, QK_GENERAL); break;
+    case 15: D2PC_CB_BSC(7, QK_STEREO); break;
+    case 18: D2PC_CB_BSC(9, QK_GENERAL); break;
+    case 19: D2PC_CB_BSC(9, QK_STEREO); break;
+    case 22: D2PC_CB_BSC(11, QK_GENERAL); break;
+    case 23: D2PC_CB_BSC(11, QK_STEREO); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef D2PC_CB_BSC
   return hipGetLastError();
 }
 

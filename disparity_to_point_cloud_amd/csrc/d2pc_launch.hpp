@@ -95,6 +95,10 @@ hipError_t launch_parity(const LaunchArgs &a);
 // a.out_index (nullable), a.counts (nullable), a.q*, a.stream as in launch_parity
 hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src, int ksize);
 hipError_t launch_compact(const LaunchArgs &a);
+// the same in COMPACT mode (k_callback_bs_compact): a.state / a.state_bytes (callback_compact_state_bytes; the
+// frame stride it returns goes into a.geom.frame_state_stride), a.stats and a.counts are required
+size_t callback_compact_state_bytes(uint32_t tiles_x, uint32_t tiles_y, uint32_t n_frames, uint32_t *frame_stride);
+hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const void *src, int ksize);
 
 // Device calibration for bench.py (d2pc_membench.hip): a plain dwordx4 fill and a dwordx4 copy, the two
 // streaming shapes the roofline fraction of the reprojection kernel is read against on the SAME device
