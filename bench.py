@@ -605,7 +605,7 @@ def main():
                                            b4.points.data_ptr(), b4.index.data_ptr(), b4.stride, b4.counts.data_ptr(), s3)
 
             rec = {}
-            for fused in (1, 0):
+            for fused in (2, 1, 0):
                 c4.set_tuning("callback_fused_compact", fused)
                 _BodyCompact().launch()
                 torch.cuda.synchronize()
@@ -622,7 +622,8 @@ def main():
                         "surviving points in row-major order, row counts handed over inside the launch)",
                 "as_two_launches_ms": kms2, "as_two_launches_ms_spread": rec[0][0],
                 "as_two_launches_what": "k_median_bs_u8<11> over the inset ROI + k_compact_onepass<U8>",
-                "speedup_over_two_launches": round(kms2 / kms, 3)}
+                "speedup_over_two_launches": round(kms2 / kms, 3),
+                "pipelined_form_ms_spread": rec[2][0], "pipelined_form_counters": rec[2][1]}
             del raw4
         del b4
         c4.close()

@@ -103,7 +103,11 @@ struct d2pc_ctx {
   CompactStats *d_stats = nullptr;  // single-pass counters, added to by the launches' blocks (d2pc_compact_stats)
   int membench_blocks_per_cu = 8;
   // d2pc_process_mono_device: two internal streams + scratch for the filtered frames
-  int cb_fused_compact = 1;      // ... and the COMPACT form of that kernel (k_callback_bs_compact); 0 = two launches in COMPACT mode
+  int cb_fused_compact = 2;      // ... and the COMPACT form of that kernel: 2 = persistent blocks, software-pipelined over their
+                                 // tiles (k_callback_bs_compact_pipe; the default: 16 x 4K with 30 % holes + indices 711 us
+                                 // against 758 us for form 1 and 963 us as two launches, profiles/r03_callback_compact.txt);
+                                 // 1 = one tile per block (k_callback_bs_compact); 0 = two launches in COMPACT mode
+  int cb_pipe_blocks_per_cu = 3; // the pipelined form's persistent blocks per CU (LDS and registers admit 3)
   int cb_fused = 1;              // d2pc_process_mono_device, PARITY: median + points in one kernel, tile by tile (k_callback_bs:
                                  // bit-sliced median, the tile's points from LDS) when the launch is large enough for the
                                  // bit-sliced filter; 0 = always the filter launch followed by the reprojection launch
@@ -822,7 +826,8 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "callback_chunks") && value >= 0 && value <= 64) ctx->cb_chunks = value;
   else if (!strcmp(key, "callback_fused") && (value == 0 || value == 1)) ctx->cb_fused = value;
-  else if (!strcmp(key, "callback_fused_compact") && (value == 0 || value == 1)) ctx->cb_fused_compact = value;
+  else if (!strcmp(key, "callback_fused_compact") && value >= 0 && value <= 2) ctx->cb_fused_compact = value;
+  else if (!strcmp(key, "callback_pipe_blocks_per_cu") && value >= 1 && value <= 8) ctx->cb_pipe_blocks_per_cu = value;
   else if (!strcmp(key, "host_direct_read") && (value == 0 || value == 1)) ctx->host_direct_read = value;
   else if (!strcmp(key, "median_algo") && value >= 0 && value <= 2) ctx->median_algo = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
@@ -1282,7 +1287,7 @@ int callback_event(d2pc_ctx *ctx, size_t i, hipEvent_t *e) {
 // blocks resident at once (k_callback_bs_compact's hand-off), i.e. ROIs up to 128 x 256 pixels wide.
 bool callback_one_kernel_ok(const d2pc_ctx *ctx, bool compact, const Geom &g) {
   if (!compact) return true;
-  return ctx->cb_fused_compact == 1 && (g.roi_w + 255u) / 256u <= kCbMaxTilesX;
+  return ctx->cb_fused_compact >= 1 && (g.roi_w + 255u) / 256u <= kCbMaxTilesX;
 }
 
 }  // namespace
@@ -1418,6 +1423,18 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
           a.state = sb->p;
           sb->algo = 2;  // its header carries the hand-off's timeout flag, like the single pass's
           a.geom = g;
+          a.compact_algo = 1;
+          if (ctx->cb_fused_compact == 2) {
+            // persistent blocks, a multiple of the frame count; every frame needs more blocks than a band has tiles
+            // (or as many as it has tiles): otherwise the one-tile-per-block form serves the launch
+            const uint32_t tiles_x = (g.roi_w + 255u) / 256u, tpf = tiles_x * ((g.roi_n / g.roi_w + 31u) / 32u);
+            uint32_t per_frame = uint32_t(ctx->cu_count * ctx->cb_pipe_blocks_per_cu) / uint32_t(nf);
+            if (per_frame > tpf) per_frame = tpf;
+            if (per_frame > tiles_x || per_frame == tpf) {
+              a.grid = per_frame * uint32_t(nf);
+              a.compact_algo = 2;
+            }
+          }
           D2PC_HIP(ctx, launch_callback_bs_compact(a, m, kin, median_ksize));
           if (!sb->captured) {
             D2PC_HIP(ctx, hipEventRecord(sb->done, sr));

@@ -222,52 +222,78 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
 
 }  // namespace bs
 
-// Stages 1-4 of one 256 x 32 tile whose first output pixel is (x0, y0) of frame `fsrc`: afterwards (the function
-// ends with the block barrier) the tile's filtered bytes lie in s_w, read as bytes, OUT_STRIDE per row, and
-// s_raw is free.  Called by all THREADS threads of the block.
+// Stage 1a of one 256 x 32 tile whose first output pixel is (x0, y0) of frame `fsrc`: the tile's input rows (+ halo),
+// replicated at the image edges, requested as 16-byte runs into registers -- all of a thread's loads issued together
+// (a loop with the edge test inside serialises a dozen global round trips per block: a third of the kernel's time).
+// Separate from the rest so that a software-pipelined caller can have the NEXT tile's rows in flight while it
+// finishes the current one (k_callback_bs_compact_pipe).
+template <int KS>
+struct MedianBsRows {
+  static constexpr int RUNS = MedianBsShape<KS>::RAW_STRIDE / 16;
+  static constexpr int TOTAL = MedianBsShape<KS>::IN_ROWS * RUNS;
+  static constexpr int PER_THREAD = (TOTAL + MedianBsShape<KS>::THREADS - 1) / MedianBsShape<KS>::THREADS;
+  uint4 v[PER_THREAD];
+};
+
+template <int KS>
+__device__ __forceinline__ void median_bs_load(MedianBsRows<KS> &rows, const uint8_t *__restrict__ fsrc, const MedianArgs &a,
+                                               const int x0, const int y0, const uint32_t tid) {
+  using S = MedianBsShape<KS>;
+  using RW = MedianBsRows<KS>;
+  constexpr int R = S::R;
+  const bool interior = x0 - R >= 0 && x0 - R + S::RAW_STRIDE <= int(a.width);  // block-uniform
+#pragma unroll
+  for (int k = 0; k < RW::PER_THREAD; ++k) {
+    const uint32_t c = tid + uint32_t(k * S::THREADS);
+    const uint32_t r = c / uint32_t(RW::RUNS), i16 = 16u * (c - r * uint32_t(RW::RUNS));
+    int iy = y0 - R + int(r);
+    iy = iy < 0 ? 0 : iy >= int(a.height) ? int(a.height) - 1 : iy;  // (also keeps the rows of c >= TOTAL in bounds)
+    const uint8_t *row = fsrc + uint64_t(iy) * a.src_row_stride;
+    const int x = x0 - R + int(i16);
+    if (interior) {
+      __builtin_memcpy(&rows.v[k], row + x, 16);
+    } else {
+      uint32_t d[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        d[q] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int ix = x + 4 * q + e;
+          ix = ix < 0 ? 0 : ix >= int(a.width) ? int(a.width) - 1 : ix;
+          d[q] |= uint32_t(row[ix]) << (8 * e);
+        }
+      }
+      rows.v[k] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows, uint32_t (&s_w)[MedianBsShape<KS>::W_WORDS],
+                                                    uint32_t (&s_raw)[MedianBsShape<KS>::RAW_WORDS], const uint32_t tid);
+
+// Stages 1-4 of one tile: afterwards (the function ends with the block barrier) the tile's filtered bytes lie in s_w,
+// read as bytes, OUT_STRIDE per row, and s_raw is free.  Called by all THREADS threads of the block.
 template <int KS>
 __device__ __forceinline__ void median_bs_tile(const uint8_t *__restrict__ fsrc, const MedianArgs &a, const int x0, const int y0,
                                                uint32_t (&s_w)[MedianBsShape<KS>::W_WORDS],
                                                uint32_t (&s_raw)[MedianBsShape<KS>::RAW_WORDS], const uint32_t tid) {
+  MedianBsRows<KS> rows;
+  median_bs_load<KS>(rows, fsrc, a, x0, y0, tid);
+  median_bs_tile_from<KS>(rows, s_w, s_raw, tid);
+}
+
+// Stages 1b-4: the requested rows as bytes into LDS, then plane words, the select, and the bytes back.
+template <int KS>
+__device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows, uint32_t (&s_w)[MedianBsShape<KS>::W_WORDS],
+                                                    uint32_t (&s_raw)[MedianBsShape<KS>::RAW_WORDS], const uint32_t tid) {
   using S = MedianBsShape<KS>;
-  constexpr int R = S::R;
-  // ---- 1. the tile's input rows (+ halo), replicated at the image edges, as bytes in LDS ------------
-  // 16-byte runs, all of a thread's loads issued before the first LDS store (a loop with the edge test
-  // inside serialises a dozen global round trips per block: a third of the kernel's time)
-  {
-    constexpr int RUNS = S::RAW_STRIDE / 16, TOTAL = S::IN_ROWS * RUNS, PER_THREAD = (TOTAL + S::THREADS - 1) / S::THREADS;
-    const bool interior = x0 - R >= 0 && x0 - R + S::RAW_STRIDE <= int(a.width);  // block-uniform
-    uint4 v[PER_THREAD];
+  using RW = MedianBsRows<KS>;
 #pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k) {
-      const uint32_t c = tid + uint32_t(k * S::THREADS);
-      const uint32_t r = c / uint32_t(RUNS), i16 = 16u * (c - r * uint32_t(RUNS));
-      int iy = y0 - R + int(r);
-      iy = iy < 0 ? 0 : iy >= int(a.height) ? int(a.height) - 1 : iy;  // (also keeps the rows of c >= TOTAL in bounds)
-      const uint8_t *row = fsrc + uint64_t(iy) * a.src_row_stride;
-      const int x = x0 - R + int(i16);
-      if (interior) {
-        __builtin_memcpy(&v[k], row + x, 16);
-      } else {
-        uint32_t d[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          d[q] = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            int ix = x + 4 * q + e;
-            ix = ix < 0 ? 0 : ix >= int(a.width) ? int(a.width) - 1 : ix;
-            d[q] |= uint32_t(row[ix]) << (8 * e);
-          }
-        }
-        v[k] = make_uint4(d[0], d[1], d[2], d[3]);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k) {
-      const uint32_t c = tid + uint32_t(k * S::THREADS);
-      if (c < uint32_t(TOTAL)) reinterpret_cast<uint4 *>(s_raw)[c] = v[k];
-    }
+  for (int k = 0; k < RW::PER_THREAD; ++k) {
+    const uint32_t c = tid + uint32_t(k * S::THREADS);
+    if (c < uint32_t(RW::TOTAL)) reinterpret_cast<uint4 *>(s_raw)[c] = rows.v[k];
   }
   __syncthreads();
 

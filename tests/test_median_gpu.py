@@ -547,7 +547,7 @@ def test_tile_fused_compact_kernel_matches_the_two_launches_and_the_oracle(gener
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
         s = torch.cuda.current_stream().cuda_stream
-        for fused in (1, 0):
+        for fused in (2, 1, 0):   # pipelined persistent form, one tile per block, two launches
             ctx.set_tuning("callback_fused_compact", fused)
             for _ in range(3):
                 b.points.fill_(0)
@@ -560,9 +560,10 @@ def test_tile_fused_compact_kernel_matches_the_two_launches_and_the_oracle(gener
             res[fused] = (b.points.cpu().numpy().copy(), b.index.cpu().numpy().copy(), b.counts.cpu().numpy().copy())
         st = ctx.compact_stats()
         assert st["timeouts"] == 0
-    assert np.array_equal(res[1][2], res[0][2]), "counts differ"
-    for a, c in zip(res[1], res[0]):
-        assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), "tile-fused COMPACT kernel differs from the two launches"
+    for fused in (1, 2):
+        assert np.array_equal(res[fused][2], res[0][2]), f"counts differ (form {fused})"
+        for a, c in zip(res[fused], res[0]):
+            assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), f"tile-fused COMPACT kernel (form {fused}) differs from the two launches"
     pts, idx = res[1][0].reshape(n, -1, 4), res[1][1].view(np.uint32)
     for f in range(n):
         want, wi = oracle.reproject_compact(oracle.median_u8(np.ascontiguousarray(imgs[f, :, :w]), k), q, border=border, scale=scale)
@@ -586,7 +587,7 @@ def test_tile_fused_compact_kernel_with_degenerate_scales_and_a_disparity_floor(
     with d2pc.Context(q=d2pc.make_q(), border=7, mode=d2pc.MODE_COMPACT, min_disparity=dmin) as ctx:
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
-        for fused in (1, 0):
+        for fused in (2, 1, 0):
             ctx.set_tuning("callback_fused_compact", fused)
             b.points.fill_(0)
             b.index.fill_(-1)
@@ -595,11 +596,13 @@ def test_tile_fused_compact_kernel_with_degenerate_scales_and_a_disparity_floor(
             torch.cuda.synchronize()
             ctx.check_async_error()
             res[fused] = (b.points.cpu().numpy().view(np.uint32).copy(), b.index.cpu().numpy().copy(), b.counts.cpu().numpy().copy())
-    for a, c in zip(res[1], res[0]):
-        assert np.array_equal(a, c)
+    for fused in (1, 2):
+        for a, c in zip(res[fused], res[0]):
+            assert np.array_equal(a, c), f"form {fused}"
 
 
-def test_tile_fused_compact_kernel_is_capturable_and_runs_on_two_streams():
+@pytest.mark.parametrize("form", [1, 2])
+def test_tile_fused_compact_kernel_is_capturable_and_runs_on_two_streams(form):
     """Captured without a warm-up call after d2pc_reserve_mono (its hand-off state is the capture's own), replayed
     onto wiped outputs; and two different batches in flight on two streams keep their own state."""
     from disparity_to_point_cloud_amd.torch_api import DeviceBatch
@@ -610,6 +613,7 @@ def test_tile_fused_compact_kernel_is_capturable_and_runs_on_two_streams():
     srcs = [torch.from_numpy(x).cuda() for x in sets]
     with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
         ctx.set_tuning("median_algo", 2)
+        ctx.set_tuning("callback_fused_compact", form)
         bs = [DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True) for _ in range(2)]
         ctx.reserve_mono(d2pc.DTYPE_U8, w, h, n)
         torch.cuda.synchronize()
@@ -659,7 +663,7 @@ def test_callback_body_compact_at_the_benchmark_size_one_kernel_equals_two_launc
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
         s = torch.cuda.current_stream().cuda_stream
         keep = {}
-        for fused in (1, 0):
+        for fused in (2, 1, 0):
             ctx.set_tuning("callback_fused_compact", fused)
             b.points.fill_(0)
             b.index.fill_(-1)
@@ -669,11 +673,12 @@ def test_callback_body_compact_at_the_benchmark_size_one_kernel_equals_two_launc
             torch.cuda.synchronize()
             ctx.check_async_error()
             keep[fused] = (b.points.view(torch.int32).clone(), b.index.clone(), b.counts.clone())
-        for x, y in zip(keep[1], keep[0]):
-            assert torch.equal(x, y)
+        for fused in (1, 2):
+            for x, y in zip(keep[fused], keep[0]):
+                assert torch.equal(x, y), f"form {fused}"
         res = b.results()
         st = ctx.compact_stats()
-        assert st["timeouts"] == 0 and st["tiles"] >= 16 * 15 * 65
+        assert st["timeouts"] == 0 and st["tiles"] >= 2 * 16 * 15 * 65
     imgs = src.cpu().numpy()
     for f in (0, 11):
         want, wi = oracle.reproject_compact(oracle.median_u8(imgs[f], 11), q, border=40, scale=0.125)
