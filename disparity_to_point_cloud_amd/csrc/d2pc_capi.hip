@@ -80,6 +80,7 @@ struct d2pc_ctx {
   int onepass_blocks_per_cu = 0;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each: 4 fit); 0 = choose per launch
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
+  int general_q_form = 0;        // 0: OpenCV 3/4's association bit for bit; 1: fused multiply-adds (round 2's form)
   int no_vec_rows = 0;
   int stage_timing = 0;          // record per-stage HIP events in the synchronous host entry points
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -410,6 +411,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   memcpy(a.q.q, ctx->q, sizeof a.q.q);
   a.qs = ctx->qs;
   a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
+  a.general_q_fma = ctx->general_q_form == 1;
   // 16-B row loads need every aligned group of four ROI pixels to sit in one
   // row at a 16-B aligned address
   a.vec_rows = !ctx->no_vec_rows && dtype == D2PC_DTYPE_F32 && g.roi_w % 4 == 0 && g.border % 4 == 0 &&
@@ -821,6 +823,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 0 && value <= 64) ctx->onepass_blocks_per_cu = value;
   else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
+  else if (!strcmp(key, "general_q_form") && (value == 0 || value == 1)) ctx->general_q_form = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
@@ -1413,6 +1416,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
         a.qs = ctx->qs;
         a.qs.w_safe = w_safe_for(ctx, g);
         a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
+        a.general_q_fma = ctx->general_q_form == 1;
         if (compact) {  // the COMPACT form hands row counts over between the tiles of a band: its own state
           uint32_t stride = 0;
           a.state_bytes = callback_compact_state_bytes((g.roi_w + 255u) / 256u, (g.roi_n / g.roi_w + 31u) / 32u, uint32_t(nf), &stride);

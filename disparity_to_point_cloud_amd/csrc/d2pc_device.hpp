@@ -63,6 +63,8 @@ struct Geom {
 // i.e. one copy per wave with no LDS or vector-memory traffic at all.
 struct QMat {
   double q[16];
+  uint32_t fma_form;  // 0: OpenCV 3/4's association, bit for bit (default); 1: fused multiply-adds (tuning "general_q_form")
+  uint32_t pad;
 };
 
 // The structure cv::stereoRectify always produces (hpp:104):

@@ -127,21 +127,42 @@ struct QArg<QK_STEREO> {
 // holds for d == FLT_MAX only.  One compare + select; X and Y stay as computed.
 __device__ __forceinline__ float big_z_rule(float d, float Z) { return d == 3.402823466e+38f ? 10000.0f : Z; }
 
-// cpp:63-64  [X Y Z W] = Q.(u,v,d,1); (X/W, Y/W, Z/W) evaluated in fp64 with
-// the association of OpenCV 2.4's loop: (row term + u*q_0) + d*q_2, then
-// iW = 1./W and num*iW, one cast to fp32 at the end.
+// cpp:63-64  [X Y Z W] = Q.(u,v,d,1); (X/W, Y/W, Z/W) for a GENERAL Q, in ONE published association, bit for bit:
+// OpenCV 3.x/4.x's reprojectImageTo3D (calib3d/calibration.cpp + core/matx.hpp; oracle/d2pc_oracle.c FORM_CV4)
+//     Vec4d h = Q * Vec4d(x, y, d, 1)   every row s = 0; s += q_k * b_k, left to right, each product and sum rounded
+//     Vec3f p = Vec3d(h.val)            the three numerators cast to float
+//     p /= h[3]                         ia = 1./h[3]; p[i] = float(p[i] * ia), the product formed in double
+// (no contraction: #pragma clang fp contract(off)).  Round 2 evaluated the rows with fused multiply-adds, which matched
+// neither published form where a dense Q makes a numerator cancel (tens of float ulp); that form stays behind the
+// tuning key "general_q_form" = 1 for comparison.  cv::stereoRectify's Q takes the specialised path below.
 __device__ __forceinline__ void reproject(const QArg<QK_GENERAL> &A, uint32_t u, uint32_t v, float d, float &X,
                                           float &Y, float &Z) {
   const double *q = A.m.q;
   const double du = double(u), dv = double(v), dd = double(d);
-  const double nx = fma(q[2], dd, fma(q[0], du, fma(q[1], dv, q[3])));
-  const double ny = fma(q[6], dd, fma(q[4], du, fma(q[5], dv, q[7])));
-  const double nz = fma(q[10], dd, fma(q[8], du, fma(q[9], dv, q[11])));
-  const double nw = fma(q[14], dd, fma(q[12], du, fma(q[13], dv, q[15])));
-  const double iw = 1.0 / nw;
-  X = float(nx * iw);
-  Y = float(ny * iw);
-  Z = big_z_rule(d, float(nz * iw));
+  if (A.m.fma_form) {  // (wave-uniform)
+    const double nx = fma(q[2], dd, fma(q[0], du, fma(q[1], dv, q[3])));
+    const double ny = fma(q[6], dd, fma(q[4], du, fma(q[5], dv, q[7])));
+    const double nz = fma(q[10], dd, fma(q[8], du, fma(q[9], dv, q[11])));
+    const double nw = fma(q[14], dd, fma(q[12], du, fma(q[13], dv, q[15])));
+    const double iw = 1.0 / nw;
+    X = float(nx * iw);
+    Y = float(ny * iw);
+    Z = big_z_rule(d, float(nz * iw));
+    return;
+  }
+  double h[4];
+  {
+    // every product and every sum rounds on its own, as in the x86-64 builds of OpenCV: no fused multiply-add
+    // (HIP's __dmul_rn / __dadd_rn are plain operators and would be contracted like them)
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      h[r] = (((0.0 + q[4 * r] * du) + q[4 * r + 1] * dv) + q[4 * r + 2] * dd) + q[4 * r + 3];  // (q_3 * 1.0 is exact)
+  }
+  const double ia = 1.0 / h[3];
+  X = float(double(float(h[0])) * ia);
+  Y = float(double(float(h[1])) * ia);
+  Z = big_z_rule(d, float(double(float(h[2])) * ia));
 }
 
 // Same evaluation with Q = [1 0 0 cx; 0 1 0 cy; 0 0 0 f; 0 0 a b]: the
@@ -172,10 +193,16 @@ __device__ __forceinline__ void store_point(float4 *frame_out, uint32_t point, f
   st<NT>(reinterpret_cast<v4f *>(reinterpret_cast<uint8_t *>(frame_out) + (point << 4)), p);
 }
 
+#ifndef D2PC_INDEX_STORE_NT
+#define D2PC_INDEX_STORE_NT 0
+#endif
+#ifndef D2PC_ONEPASS_INDEX_NT
+#define D2PC_ONEPASS_INDEX_NT 0
+#endif
 __device__ __forceinline__ void store_index(uint32_t *frame_idx, uint32_t point, uint32_t pix) {
   // plain store: a wave writes only 256 B of indices (partial lines that L2 must merge with its
   // neighbours' pieces); nt here cost +20 % on the 30 %-holes + index case
-  *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(frame_idx) + (point << 2)) = pix;
+  st<D2PC_INDEX_STORE_NT != 0>(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(frame_idx) + (point << 2)), pix);
 }
 
 // Exact validity of a STEREO-structured point WITHOUT evaluating it (used by
@@ -960,7 +987,10 @@ __device__ __forceinline__ void tile_scatter_lean(const QArg<QK> &Q, const Geom 
         const v4f p = {X, Y, Z, 1.0f};
         if (D2PC_ONEPASS_STORE_NT) __builtin_nontemporal_store(p, (gv4f *)(fout + (uint64_t(pos) << 4)));
         else *(gv4f *)(fout + (uint64_t(pos) << 4)) = p;
-        if constexpr (IDX) *(gu32 *)(fidx + (uint64_t(pos) << 2)) = vv * g.width + uu;
+        if constexpr (IDX) {
+          if (D2PC_ONEPASS_INDEX_NT) __builtin_nontemporal_store(vv * g.width + uu, (gu32 *)(fidx + (uint64_t(pos) << 2)));
+          else *(gu32 *)(fidx + (uint64_t(pos) << 2)) = vv * g.width + uu;
+        }
       }
     }
   }
@@ -1721,6 +1751,8 @@ template <>
 QArg<QK_GENERAL> make_qarg<QK_GENERAL>(const LaunchArgs &a) {
   QArg<QK_GENERAL> r;
   r.m = a.q;
+  r.m.fma_form = a.general_q_fma ? 1u : 0u;
+  r.m.pad = 0;
   return r;
 }
 template <>

@@ -124,10 +124,16 @@ static void reproject_row(const void *row, int dtype, float scale, int y,
       for (int r = 0; r < 4; r++)
         h[r] = 0.0 + q[4 * r] * x + q[4 * r + 1] * y + q[4 * r + 2] * d +
                q[4 * r + 3] * 1.0; /* Matx product: s = 0; s += a_k*b_k */
+      /* Vec3f p = Vec3d(h.val): the numerators exist as floats before the division (p /= h[3] multiplies each
+       * by ia = 1./h[3] in double and casts back).  `volatile`: gcc 11.4 -O3 vectorises the x/y pair and drops
+       * the float round trip of (float)h * ia there (seen in the disassembly: vmulpd + one vcvtpd2ps), i.e. the
+       * binary computed (float)(h * ia) for x and y -- one cast less than the published form.
+       * tests/test_oracle.py pins the binary against a numpy restatement of both forms. */
+      volatile float p0 = (float)h[0], p1 = (float)h[1], p2 = (float)h[2];
       const double ia = 1. / h[3];
-      out[x - u0].x = (float)((float)h[0] * ia);
-      out[x - u0].y = (float)((float)h[1] * ia);
-      out[x - u0].z = (float)((float)h[2] * ia);
+      out[x - u0].x = (float)((double)p0 * ia);
+      out[x - u0].y = (float)((double)p1 * ia);
+      out[x - u0].z = (float)((double)p2 * ia);
       if (fabs(d - D2PC_ORACLE_MIN_DISPARITY) <= FLT_EPSILON)
         out[x - u0].z = (float)D2PC_ORACLE_BIG_Z;
     }

@@ -340,10 +340,11 @@ def test_tile_fused_callback_kernel_matches_the_two_launches_and_the_oracle(gene
     for a, c in zip(res[1], res[0]):
         assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), "tile-fused kernel differs from the two launches"
     pts = res[1][0].reshape(n, -1, 4)
+    form, ulp = (oracle.FORM_CV4, 0) if general_q else (oracle.FORM_CV24, 1)  # the general kernel IS OpenCV 4's association
     for f in range(n):
-        want = oracle.reproject(oracle.median_u8(np.ascontiguousarray(imgs[f, :, :w]), k), q, border=border, scale=scale)
+        want = oracle.reproject(oracle.median_u8(np.ascontiguousarray(imgs[f, :, :w]), k), q, border=border, scale=scale, form=form)
         assert res[1][2].view(np.uint32)[f] == len(want)
-        assert_points_close(pts[f][:len(want)], want, max_ulp=1, rel=1e-5, what=f"frame {f}")
+        assert_points_close(pts[f][:len(want)], want, max_ulp=ulp, rel=1e-5, what=f"frame {f}")
 
 
 @pytest.mark.parametrize("scale", [float("inf"), float("nan"), -0.125, 3.0e38, 0.0, 1e-45])
@@ -565,12 +566,14 @@ def test_tile_fused_compact_kernel_matches_the_two_launches_and_the_oracle(gener
         for a, c in zip(res[fused], res[0]):
             assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), f"tile-fused COMPACT kernel (form {fused}) differs from the two launches"
     pts, idx = res[1][0].reshape(n, -1, 4), res[1][1].view(np.uint32)
+    form, ulp = (oracle.FORM_CV4, 0) if general_q else (oracle.FORM_CV24, 1)
     for f in range(n):
-        want, wi = oracle.reproject_compact(oracle.median_u8(np.ascontiguousarray(imgs[f, :, :w]), k), q, border=border, scale=scale)
+        want, wi = oracle.reproject_compact(oracle.median_u8(np.ascontiguousarray(imgs[f, :, :w]), k), q, border=border, scale=scale,
+                                            form=form)
         assert res[1][2].view(np.uint32)[f] == len(want)
         assert np.array_equal(idx[f][:len(wi)], wi)
         if len(want):
-            assert_points_close(pts[f][:len(want)], want, max_ulp=1, rel=1e-5, what=f"frame {f}")
+            assert_points_close(pts[f][:len(want)], want, max_ulp=ulp, rel=1e-5, what=f"frame {f}")
 
 
 @pytest.mark.parametrize("scale,dmin", [(float("inf"), -np.inf), (float("nan"), -np.inf), (-0.125, -np.inf), (3.0e38, -np.inf),

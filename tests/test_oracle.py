@@ -324,3 +324,66 @@ def test_oracle_under_asan_ubsan():
     p = subprocess.run([os.path.join(here, "_selftest_asan")], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "oracle selftest ok" in p.stdout
+
+
+def _numpy_cv4(disp, q, border):
+    """OpenCV 3/4's reprojectImageTo3D association in numpy float64 / float32 operations, one rounding per
+    operation: Vec4d h = Q * (x, y, d, 1) left to right, Vec3f p = h (cast), p /= h[3] (ia = 1./h[3], product in
+    double, one cast)."""
+    h, w = disp.shape
+    v, u = np.mgrid[border:h - border, border:w - border]
+    x, y, d = u.astype(np.float64), v.astype(np.float64), disp[border:h - border, border:w - border].astype(np.float64)
+    hh = []
+    with np.errstate(all="ignore"):
+        for r in range(4):
+            s = 0.0 + q[4 * r] * x
+            s = s + q[4 * r + 1] * y
+            s = s + q[4 * r + 2] * d
+            hh.append(s + q[4 * r + 3])
+        ia = 1.0 / hh[3]
+        return np.stack([(hh[c].astype(np.float32).astype(np.float64) * ia).astype(np.float32) for c in range(3)], axis=-1)
+
+
+def _numpy_cv24(disp, q, border):
+    """OpenCV 2.4's loop: per row qx = q01*y + q03 ..., then qx += q00 per column (replayed from column 0),
+    iW = 1./(qw + q32*d), X = (qx + q02*d)*iW, one cast."""
+    h, w = disp.shape
+    out = np.empty((h - 2 * border, w - 2 * border, 3), dtype=np.float32)
+    with np.errstate(all="ignore"):
+        for yi, y in enumerate(range(border, h - border)):
+            acc = [np.float64(q[4 * r + 1]) * y + q[4 * r + 3] for r in range(4)]
+            cols = []
+            for r in range(4):  # the x-recurrence: a running sum of q_r0, one rounding per step
+                steps = np.full(w, q[4 * r], dtype=np.float64)
+                steps[0] = acc[r]
+                run = np.empty(w, dtype=np.float64)
+                a = steps[0]
+                run[0] = a
+                for xx in range(1, w):
+                    a = a + q[4 * r]
+                    run[xx] = a
+                cols.append(run[border:w - border])
+            d = disp[y, border:w - border].astype(np.float64)
+            iw = 1.0 / (cols[3] + q[14] * d)
+            for c, k in enumerate((2, 6, 10)):
+                out[yi, :, c] = ((cols[c] + q[k] * d) * iw).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("form", [oracle.FORM_CV24, oracle.FORM_CV4])
+def test_oracle_binary_equals_a_numpy_restatement_bit_for_bit(form):
+    """Pins the COMPILED oracle against compiler liberties (round 3: gcc 11.4 -O3 had vectorised FORM_CV4's x/y pair
+    and dropped the float cast of the numerators there -- the binary did not compute what its source says)."""
+    rng = np.random.default_rng(5)
+    for dense in (True, False):
+        q = rng.uniform(-2, 2, 16)
+        q[12:14] = rng.uniform(0, 1e-3, 2)
+        q[14], q[15] = rng.uniform(0.01, 1), rng.uniform(0.1, 2)
+        if not dense:
+            q = oracle.make_q()
+        disp = rng.uniform(0.5, 128, size=(61, 83)).astype(np.float32)
+        disp[rng.random(disp.shape) < 0.2] = 0
+        got = oracle.reproject(disp, q, border=3, form=form).reshape(55, 77, 4)[..., :3]
+        want = (_numpy_cv4 if form == oracle.FORM_CV4 else _numpy_cv24)(disp, q, 3)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), f"form {form}, dense {dense}: {int((~same).sum())} of {same.size} values differ"

@@ -46,6 +46,19 @@ def test_golden_exact_rational(golden, name):
     disp = golden[name + "__disp"]
     with ctx_for(q, border=border) as ctx:
         got = ctx.process(disp)
+        ctx.set_tuning("general_q_form", 1)   # round 2's fused multiply-add evaluation of a general Q
+        got_fma = ctx.process(disp)
+    if name.endswith("dense_q"):
+        # a GENERAL Q is evaluated in OpenCV 3/4's association, bit for bit (oracle FORM_CV4): two casts => within
+        # 2 ulp of the exact value, and its float-cast numerators overflow where d ~ FLT_MAX meets a dense Q (a real
+        # property of that published form: tests/test_oracle.py)
+        want4 = oracle.reproject(disp, q, border=border, form=oracle.FORM_CV4)
+        assert np.array_equal(got.view(np.uint32), want4.view(np.uint32)), "general Q is not OpenCV 4's form bit for bit"
+        if not name.startswith("E_"):
+            assert_points_close(got, exp, max_ulp=2, rel=REL_TOL, what=name)
+        assert_points_close(got_fma, exp, max_ulp=MAX_ULP, rel=REL_TOL, what=name + " (fma form)")
+        return
+    assert np.array_equal(got.view(np.uint32), got_fma.view(np.uint32))   # the key only touches the general path
     assert_points_close(got, exp, max_ulp=MAX_ULP, rel=REL_TOL, what=name)
     assert (ulp_distance(got[:, :3], exp[:, :3]) == 0).mean() > 0.99
 
@@ -160,10 +173,11 @@ def test_ragged_sizes(w, h, border):
     q = rng.uniform(-1, 1, 16)
     q[12:16] = [2e-4, 1e-4, 0.03, 0.7]
     disp = rng.uniform(0.5, 128, size=(h, w)).astype(np.float32)
-    want = oracle.reproject(disp, q, border=border)
+    want = oracle.reproject(disp, q, border=border, form=oracle.FORM_CV4)   # a dense Q: OpenCV 3/4's association, bit for bit
     with ctx_for(q, border=border) as ctx:
         got, idx = ctx.process(disp, want_index=True)
-    assert_points_close(got, want, max_ulp=MAX_ULP, rel=REL_TOL, what=f"{w}x{h}")
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{w}x{h}"
+    assert_points_close(got, oracle.reproject(disp, q, border=border), max_ulp=8, rel=REL_TOL, what=f"{w}x{h} vs the 2.4 form")
     v, u = np.mgrid[border : h - border, border : w - border]
     assert np.array_equal(idx, (v * w + u).reshape(-1).astype(np.uint32))
 
@@ -269,13 +283,24 @@ def test_compact_tiny_w_takes_exact_slow_path(algo):
 
 
 def test_general_and_stereo_kernels_agree_bitwise(q_default):
-    """The stereoRectify-structured specialisation drops only exact products:
-    it must reproduce the general kernel bit for bit, NaN/inf inputs included."""
+    """The stereoRectify-structured specialisation drops only exact products of the fused multiply-add evaluation
+    (tuning general_q_form = 1): it must reproduce that general kernel bit for bit, NaN/inf inputs included.  The
+    DEFAULT general evaluation is OpenCV 3/4's association: checked against the oracle's FORM_CV4 bit for bit."""
     disp = synth_disparity(3, 7, 700, 500, "holes")
     disp[100, 100:110] = [np.nan, np.inf, -np.inf, -1.0, 1e-30, 3e38, 0.0, -0.0, 1e-45, 5.0]
     with ctx_for(q_default) as ctx:
         a = ctx.process(disp)
         ctx.set_tuning("force_general_q", 1)
+        b4 = ctx.process(disp)
+        w4 = oracle.reproject(disp, q_default, border=40, form=oracle.FORM_CV4)
+        nan4 = np.isnan(w4)
+        assert np.array_equal(nan4, np.isnan(b4)) and np.array_equal(b4.view(np.uint32)[~nan4], w4.view(np.uint32)[~nan4])
+        ctx.set_mode(d2pc.MODE_COMPACT)
+        c4, i4 = ctx.process(disp, want_index=True)
+        wc4, wi4 = oracle.reproject_compact(disp, q_default, border=40, form=oracle.FORM_CV4)
+        assert np.array_equal(i4, wi4) and np.array_equal(c4.view(np.uint32), wc4.view(np.uint32))
+        ctx.set_mode(d2pc.MODE_PARITY)
+        ctx.set_tuning("general_q_form", 1)
         b = ctx.process(disp)
         ctx.set_mode(d2pc.MODE_COMPACT)
         cg, ig = ctx.process(disp, want_index=True)

@@ -73,16 +73,17 @@ def test_gpu_matches_oracle_on_random_inputs(q, fb, stereo):
     disp, border = fb
     if stereo:  # the structure cv::stereoRectify produces (specialised kernel)
         q = np.array([1, 0, 0, q[3], 0, 1, 0, q[7], 0, 0, 0, q[11], 0, 0, q[14], q[15]], dtype=np.float64)
-    want = oracle.reproject(disp, q, border=border)
-    wp, wi = oracle.reproject_compact(disp, q, border=border)
+    # a general Q is evaluated in OpenCV 3/4's association (oracle FORM_CV4): BIT FOR BIT, points, classes and which
+    # pixels survive; the structure cv::stereoRectify produces takes the specialised kernel: 1 ulp from the 2.4 form.
+    # derandomize: the same examples in every run.
+    form = oracle.FORM_CV24 if stereo else oracle.FORM_CV4
+    want = oracle.reproject(disp, q, border=border, form=form)
+    wp, wi = oracle.reproject_compact(disp, q, border=border, form=form)
     with d2pc.Context(q=q, border=border) as ctx:
         got = ctx.process(disp)
         ctx.set_mode(d2pc.MODE_COMPACT)
         gp, gi = ctx.process(disp, want_index=True)
-    # A dense Q can make a numerator cancel to ~1e-9 of its terms; there the oracle's per-pixel increments (OpenCV
-    # 2.4's loop) and the kernel's fused multiply-adds differ by a few float32 ulp: 8 ulp for a
-    # dense Q, 1 ulp for the structure cv::stereoRectify produces.  derandomize: the same examples in every run.
-    ulp = 1 if stereo else 8
+    ulp = 1 if stereo else 0
     assert_points_close(got, want, max_ulp=ulp, rel=1e-5)
     assert np.array_equal(gi, wi)
     assert_points_close(gp, wp, max_ulp=ulp, rel=1e-5)

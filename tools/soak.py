@@ -15,19 +15,7 @@ from helpers import assert_points_close
 
 
 def check(got, want, ulp, what):
-    if ulp is not None:
-        return assert_points_close(got, want, max_ulp=ulp, rel=1e-5, what=what)
-    # dense Q: same NaN/inf classes, pad word exact, values within 1e-5 relative OR 1e-6 of the frame's largest
-    # coordinate (a numerator that cancels almost completely has no meaningful relative error)
-    got, want = np.asarray(got).reshape(-1, 4), np.asarray(want).reshape(-1, 4)
-    assert got.shape == want.shape, what
-    assert np.array_equal(got[:, 3].view(np.uint32), want[:, 3].view(np.uint32)), what
-    g, w = got[:, :3].astype(np.float64), want[:, :3].astype(np.float64)
-    assert np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(np.isinf(g), np.isinf(w)), what
-    fin = np.isfinite(w)
-    if fin.any():
-        tol = 1e-5 * np.abs(w[fin]) + 1e-6 * np.abs(w[fin]).max()
-        assert (np.abs(g[fin] - w[fin]) <= tol).all(), what + f": max abs err {np.abs(g[fin] - w[fin]).max():.3e}"
+    return assert_points_close(got, want, max_ulp=ulp, rel=1e-5, what=what)
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
@@ -66,22 +54,21 @@ for c in range(cases):
         res = b.results()
         if m == d2pc.MODE_COMPACT:
             ctx.check_async_error()
-    # A dense Q can make a numerator cancel to ~1e-9 of its terms somewhere in a few million pixels; OpenCV 2.4's
-    # per-pixel increments (the oracle's form) and the kernel's fused multiply-adds then differ by tens of float
-    # ulps there (71 seen) -- both are legitimate double evaluations.  stereoRectify-structured Q has no such
-    # sums: 1 ulp.
-    ulp = 1 if stereo else None
+    # A general (dense) Q is evaluated in OpenCV 3/4's association: 0 ulp against the oracle's FORM_CV4 (round 2's fused
+    # multiply-adds were up to 71 float ulp from the 2.4 form where a numerator cancels: that loosened bar is gone).
+    # stereoRectify-structured Q: the specialised kernel, 1 ulp from the 2.4 form.
+    ulp, form = (1, oracle.FORM_CV24) if stereo else (0, oracle.FORM_CV4)
     what = f"case {c}: n={n} {w}x{h} b={border} {dt} {mode} algo={algo} idx={idx} holes={holes} stereo={stereo}"
     for f in range(n):
         if m == d2pc.MODE_PARITY:
-            want = oracle.reproject(frames[f], q, border=border, scale=scale)
+            want = oracle.reproject(frames[f], q, border=border, scale=scale, form=form)
             check(res[f][0], want, ulp, what)
             if idx:
                 rw, rh = max(w - 2 * border, 0), max(h - 2 * border, 0)
                 vv, uu = np.divmod(np.arange(rw * rh), max(rw, 1))
                 assert np.array_equal(res[f][1], ((vv + border) * w + uu + border).astype(np.uint32)), what
         else:
-            wp, wi = oracle.reproject_compact(frames[f], q, border=border, scale=scale)
+            wp, wi = oracle.reproject_compact(frames[f], q, border=border, scale=scale, form=form)
             assert len(res[f][0]) == len(wp), what + f" frame {f}: {len(res[f][0])} vs {len(wp)} points"
             check(res[f][0], wp, ulp, what)
             if idx:
