@@ -76,6 +76,7 @@ struct d2pc_ctx {
   // tuning (d2pc_set_tuning); defaults from tools/ab.py sweeps on MI355X
   // (fast and slow devices agree on 2048-pixel tiles and 2-4 tiles per block)
   int pxt_parity = 0, pxt_compact = 8;  // ROI pixels per thread; parity 0 = choose per launch (parity_pxt below)
+  int parity_small = 0;          // PARITY kernel form: 0 = choose, 1 = one-shot blocks of 256 * pxt pixels (pxt 1, 2, 4), 2 = tiles walked by fewer blocks
   int blocks_per_cu = 128;
   int onepass_blocks_per_cu = 0;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each: 4 fit); 0 = choose per launch
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
@@ -174,14 +175,16 @@ int grow(d2pc_ctx *ctx, void **p, size_t *cap, size_t need) {
   return D2PC_OK;
 }
 
-// PARITY tile size: launches that leave the chip with few waves of blocks (one camera frame, a few 4K frames) run
-// 2-9 % faster with 1024-pixel tiles -- more blocks per CU to hide the load latency; big batches prefer 2048
-// (interleaved sweep, profiles/r02_sweep_small_launches.txt: equal at 8 x 4K, 2048 ahead from 16 x 4K / 256 x 752x480)
+// PARITY tile shape.  Default (round 3): ONE-SHOT blocks of 512 pixels, two per thread (k_reproject_pack_small) -- against
+// the tile-walking kernel with 8 pixels per thread, interleaved on one device: 16 x 4K 427 -> 394 us (border 40), 457 -> 407 us
+// (border 0); one 4K frame 24.9 -> 23.0 us; 64 x 752x480 51.2 -> 49.6 us; never slower (profiles/r03_sweep_parity_small.txt).
+// One pixel per thread is as good for launches that fit the caches and 15 % worse for the big batch.
+// pxt_parity 4 / 8 / 16 select the tile-walking kernel (1024-pixel tiles were its best for launches of <= 32 Mpixel).
 int parity_pxt(const d2pc_ctx *ctx, int width, int height, int n_frames) {
-  if (ctx->pxt_parity) return ctx->pxt_parity;
-  const long long w = (long long)width - 2LL * ctx->cfg.border, h = (long long)height - 2LL * ctx->cfg.border;
-  const long long px = (w > 0 && h > 0 ? w * h : 0) * (long long)(n_frames > 0 ? n_frames : 1);
-  return px <= (32LL << 20) ? 4 : 8;
+  (void)width;
+  (void)height;
+  (void)n_frames;
+  return ctx->pxt_parity ? ctx->pxt_parity : 2;
 }
 
 // Validates the frame description and fills the launch geometry.
@@ -426,6 +429,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   if (a.grid == 0) a.grid = 1;
   if (ctx->cfg.mode == D2PC_MODE_PARITY) {
     a.pxt = int(g.pxt);
+    a.parity_small = g.pxt <= 2 || (ctx->parity_small == 1 && g.pxt == 4);
     D2PC_HIP(ctx, launch_parity(a));
     return D2PC_OK;
   }
@@ -818,7 +822,8 @@ int d2pc_cloud_meta_fill(const d2pc_ctx *ctx, size_t n, d2pc_cloud_meta *m) {
 
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   if (!ctx || !key) return D2PC_ERR_INVALID_ARG;
-  if (!strcmp(key, "pxt_parity") && (value == 0 || tile_shape_supported(value))) ctx->pxt_parity = value;
+  if (!strcmp(key, "pxt_parity") && (value == 0 || value == 1 || value == 2 || tile_shape_supported(value))) ctx->pxt_parity = value;
+  else if (!strcmp(key, "parity_small") && value >= 0 && value <= 2) ctx->parity_small = value;
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 0 && value <= 64) ctx->onepass_blocks_per_cu = value;

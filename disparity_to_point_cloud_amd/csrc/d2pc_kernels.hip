@@ -390,6 +390,49 @@ __global__ __launch_bounds__(kBlock) void k_reproject_pack(const uint8_t *__rest
 }
 
 // --------------------------------------------------------------------------
+// K1s: PARITY with SMALL one-shot blocks: a block is one tile of 256 * S consecutive ROI pixels (S = 1, 2 or 4),
+// thread t takes pixels base + k * 256 + t, and the grid is the tile count -- no loop over tiles.  tools/membench9.hip:
+// the same 4 B -> 16 B stream moves at 6.6 TB/s with two pixels per thread and one block per 512 pixels, against 5.7
+// TB/s with eight per thread (K1's shape) on the same device: short-lived waves keep more independent requests in
+// flight than long ones whose stores queue, in order, behind their own loads.
+// --------------------------------------------------------------------------
+template <int DT, int QK, int S>
+__global__ __launch_bounds__(kBlock) void k_reproject_pack_small(const uint8_t *__restrict__ disp, float4 *__restrict__ out,
+                                                                 uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
+                                                                 const Geom g, const QArg<QK> Q) {
+  const uint32_t t = blockIdx.x;
+  const uint32_t f = fdiv(t, g.div_tpf);
+  const uint32_t lt = t - f * g.tiles_per_frame;
+  const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
+  float4 *fout = out + uint64_t(f) * g.out_frame_stride;
+  uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
+  const uint32_t base = lt * uint32_t(kBlock * S) + threadIdx.x;
+  float d[S];
+  uint32_t uu[S], vv[S];
+#pragma unroll
+  for (int k = 0; k < S; ++k) {
+    const uint32_t i = base + uint32_t(k) * uint32_t(kBlock);
+    const uint32_t v = fdiv(i, g.div_roi_w);
+    uu[k] = i - v * g.roi_w + g.border;
+    vv[k] = v + g.border;
+    // (clamped to the frame's last ROI pixel: the tail of a frame's last tile loads in bounds and stores nothing)
+    const uint32_t off = vv[k] * g.row_stride + uu[k] * elem_bytes<DT>();
+    d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
+  }
+#pragma unroll
+  for (int k = 0; k < S; ++k) {
+    const uint32_t i = base + uint32_t(k) * uint32_t(kBlock);
+    float X, Y, Z;
+    reproject(Q, uu[k], vv[k], d[k], X, Y, Z);
+    if (i < g.roi_n) {
+      store_point<D2PC_STORE_NT != 0>(fout, i, X, Y, Z);
+      if (fidx) store_index(fidx, i, vv[k] * g.width + uu[k]);
+    }
+  }
+  if (counts && lt == 0 && threadIdx.x == 0) counts[f] = g.roi_n;
+}
+
+// --------------------------------------------------------------------------
 // K1g: the callback body TILE BY TILE -- bit-sliced k x k median of a 256 x 32 tile of the inset ROI
 // (d2pc_median_bs_tile.hpp, cpp:55-57) and, from the filtered bytes still in LDS, the tile's points
 // (cpp:60-85, PARITY).  No hand-off between blocks and no filtered image in memory: the VALU-bound filter
@@ -1839,6 +1882,23 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
   return hipGetLastError();
 }
 
+template <int DT, int QK, int S>
+static hipError_t launch_parity_small_t(const LaunchArgs &a) {
+  hipLaunchKernelGGL((k_reproject_pack_small<DT, QK, S>), dim3(a.geom.total_tiles), dim3(kBlock), 0, a.stream,
+                     static_cast<const uint8_t *>(a.disp), static_cast<float4 *>(a.out_points), a.out_index, a.counts, a.geom,
+                     make_qarg<QK>(a));
+  return hipGetLastError();
+}
+template <int QK, int S>
+static hipError_t dispatch_small(const LaunchArgs &a) {
+  switch (a.dtype) {
+    case DT_F32: return launch_parity_small_t<DT_F32, QK, S>(a);
+    case DT_U8: return launch_parity_small_t<DT_U8, QK, S>(a);
+    case DT_U16: return launch_parity_small_t<DT_U16, QK, S>(a);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <int QK, int PXT>
 static hipError_t dispatch_dtype(const LaunchArgs &a, bool compact) {
   switch (a.dtype) {
@@ -1870,6 +1930,15 @@ size_t compact_state_bytes(const Geom &g) {
 }
 
 static hipError_t dispatch(const LaunchArgs &a, bool compact) {
+  if (!compact && a.parity_small) {  // the small one-shot tiles (PARITY only)
+    const bool st = a.q_kind == QK_STEREO;
+    switch (a.pxt) {
+      case 1: return st ? dispatch_small<QK_STEREO, 1>(a) : dispatch_small<QK_GENERAL, 1>(a);
+      case 2: return st ? dispatch_small<QK_STEREO, 2>(a) : dispatch_small<QK_GENERAL, 2>(a);
+      case 4: return st ? dispatch_small<QK_STEREO, 4>(a) : dispatch_small<QK_GENERAL, 4>(a);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (a.pxt) {
     case 4: return dispatch_q<4>(a, compact);
     case 8: return dispatch_q<8>(a, compact);

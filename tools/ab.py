@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--opbpc", type=int, default=4, help="single-pass kernel: persistent blocks per CU")
     ap.add_argument("--oaligns", default="16", help="output frame stride rounded up to this many points (several: A/B)")
     ap.add_argument("--ooffs", default="0", help="output base offset in points (several: A/B)")
+    ap.add_argument("--small", type=int, default=None, help="tuning parity_small (1: one-shot blocks also for pxt 4)")
     ap.add_argument("--w", type=int, default=3840)
     ap.add_argument("--h", type=int, default=2160)
     a = ap.parse_args()
@@ -75,7 +76,11 @@ def main():
         for mode, border, pxt, bpc, nv, algo, oal, oof in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(","), oaligns, ooffs):
             m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
             ctx = capi.Context(q=capi.make_q(), border=int(border), mode=m, compact_algo=int(algo))
-            ctx.set_tuning("pxt_parity", int(pxt)); ctx.set_tuning("pxt_compact", int(pxt))
+            ctx.set_tuning("pxt_parity", int(pxt))
+            if mode == "compact":
+                ctx.set_tuning("pxt_compact", int(pxt))
+            if a.small is not None:
+                ctx.set_tuning("parity_small", a.small)
             ctx.set_tuning("blocks_per_cu", int(bpc)); ctx.set_tuning("no_vec_rows", int(nv))
             ctx.set_tuning("onepass_blocks_per_cu", a.opbpc)
             b = Cand(ctx, oal, oof)
