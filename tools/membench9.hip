@@ -57,6 +57,20 @@ template <int S, bool NT> __global__ __launch_bounds__(256) void k_expand_stride
   }
 }
 
+// block-size variants of the one-shot expansion (S = 2)
+template <int BS, int S, bool NT> __global__ __launch_bounds__(BS) void k_expand_once_bs(const float *in, v4f *out, size_t n) {
+  const size_t base = size_t(blockIdx.x) * BS * S + threadIdx.x;
+  float d[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) { const size_t i = base + size_t(j) * BS; d[j] = i < n ? in[i] : 0.f; }
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const size_t i = base + size_t(j) * BS;
+    const v4f p = {d[j], d[j] * 2.f, d[j] + 1.f, 1.f};
+    if (i < n) { if (NT) __builtin_nontemporal_store(p, out + i); else out[i] = p; }
+  }
+}
+
 template <class F> double time_us(F f) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 60; ++i) f();
@@ -86,5 +100,7 @@ int main() {
   EXP_ONCE(1, false); EXP_ONCE(1, true); EXP_ONCE(2, false); EXP_ONCE(2, true); EXP_ONCE(4, false); EXP_ONCE(4, true); EXP_ONCE(8, false); EXP_ONCE(8, true);
   EXP_ONCE(16, true);
   EXP_STR(4, true, 32768); EXP_STR(8, true, 32768); EXP_STR(8, true, 15275);
+#define EXP_BS(BS, S) printf("expand once   S=%2d nt    block %4d: %7.1f us %7.1f GB/s\n", S, BS, us = time_us([&] { hipLaunchKernelGGL((k_expand_once_bs<BS, S, true>), dim3(unsigned((n + size_t(BS) * S - 1) / (size_t(BS) * S))), dim3(BS), 0, 0, in, out, n); }), n * 20 / us / 1e3)
+  EXP_BS(64, 2); EXP_BS(128, 2); EXP_BS(256, 2); EXP_BS(512, 2); EXP_BS(1024, 2); EXP_BS(64, 4); EXP_BS(128, 4); EXP_BS(64, 8); EXP_BS(128, 3); EXP_BS(256, 3);
   return 0;
 }
