@@ -353,6 +353,9 @@ def main():
     ap.add_argument("--mode", choices=["parity", "compact"], default="parity")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the device calibration and the spread rounds behind the timed region, so that a rocprofv3 "
+                         "--stats run sees the contract's launches only (its per-kernel average is then the line's)")
     ap.add_argument("--no-host-path", action="store_true",
                     help="skip the PCIe-inclusive side measurement (its single-frame and host-memory launches would "
                          "mix into the per-kernel averages of a rocprofv3 --stats run)")
@@ -417,7 +420,7 @@ def main():
     # done about that here; the rounds after it (kernel_ms_spread) show the sustained time of the same launch.
     wall, kernel_ms = timed_steps(batch, a.steps, a.warmup, multi_gpu.barrier)
     # every rank calibrates its device on its own output buffer (plain fill / copy, >= 100 ms each)
-    cal = device_calibration(ctx, batch)
+    cal = device_calibration(ctx, batch) if not a.no_extras else None
     wall = multi_gpu.allreduce_max(wall)
     kernel_ms_max = multi_gpu.allreduce_max(kernel_ms)
     per_rank_kernel_ms = multi_gpu.allgather_floats(kernel_ms)
@@ -451,18 +454,18 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "k_reproject_pack" if mode == d2pc.MODE_PARITY else "k_compact_onepass",
+            "kernel": "k_reproject_pack_small" if mode == d2pc.MODE_PARITY else "k_compact_onepass",
             "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": round(kernel_ms, 4),
             "kernel_ms_avg_max_over_ranks": round(kernel_ms_max, 4),
             "kernel_ms_avg_per_rank": [round(x, 4) for x in per_rank_kernel_ms],
             "read_component_GBs": round(4 * a.frames * batch.roi_n / (kernel_ms * 1e-3) / 1e9, 1),
         },
     }
-    fills = multi_gpu.allgather_floats(cal["device_fill_GBs"])
-    if world > 1:
+    fills = multi_gpu.allgather_floats(cal["device_fill_GBs"] if cal else 0.0)
+    if world > 1 and cal:
         out["roofline"]["device_fill_GBs_per_rank"] = [round(x, 1) for x in fills]
         out["roofline"]["device_copy_GBs_rank0"] = cal["device_copy_GBs"]
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and cal:
         # after the contract's timed region: how much the same launch moves on this device (rounds of `steps`
         # launches until >= 100 ms), next to what the device gives a plain fill / copy
         sp = spread(timed_rounds(batch, a.steps, 0))

@@ -30,7 +30,9 @@ struct StateBuf {
   bool bound = false;
   hipEvent_t done = nullptr;     // recorded behind that launch (not while capturing)
   bool pending = false;          // `done` was recorded and has not been seen complete yet
-  int algo = 0;                  // algorithm of that launch: 2 = single pass (its header holds the timeout flag)
+  int algo = 0;                  // algorithm of that launch: 2 = single pass (its header holds the timeout flag),
+                                 // 3 = resident blocks (the flag holds the launch's epoch)
+  uint32_t epoch = 0;            // algo 3: that launch's epoch
   bool captured = false;         // a stream capture baked the pointer into a graph: never freed, moved or shared
                                  // until d2pc_release_graph_buffers
   unsigned long long capture_id = 0;
@@ -94,6 +96,7 @@ struct d2pc_ctx {
   BufPool states;                  // compaction state, one buffer per stream with COMPACT work in flight
   BufPool cb_scratch;              // d2pc_process_mono_device, two-launch form: one scratch per stream in flight
   // production counters (d2pc_compact_stats): reset by d2pc_compact_stats_reset
+  uint32_t resident_epoch = kEpochBase;  // compact_algo 3: the next launch's epoch
   uint64_t n_twopass_fallbacks = 0;  // synchronous host calls that reran a timed-out single pass with the two-pass form
   void *d_in = nullptr;      size_t in_cap = 0;
   void *d_out = nullptr;     size_t out_cap = 0;
@@ -283,6 +286,15 @@ int state_alloc(d2pc_ctx *ctx, const BufPool *pool, StateBuf &b, size_t need, si
     b.pending = false;
   }
   int st = grow(ctx, &b.p, &b.cap, need);
+  // fresh memory starts zeroed: k_compact_resident tells "published by THIS launch" from anything older by the epoch
+  // in the word, and an uninitialised word could hold any value
+  // (hipMemset of device memory may return before the fill has run, and the launches that follow go to streams
+  // that do not wait for the NULL stream: a late fill wiped a running launch's header -- its pointer to the counters
+  // included.  So: fill, then wait for it.)
+  if (st == D2PC_OK && b.p) {
+    D2PC_HIP(ctx, hipMemsetAsync(b.p, 0, b.cap, nullptr));
+    D2PC_HIP(ctx, hipStreamSynchronize(nullptr));
+  }
   if (st == D2PC_OK && need2) st = grow(ctx, &b.p2, &b.cap2, need2);
   return st;
 }
@@ -440,7 +452,13 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   // 256 x 752x480: 278 vs 290; but 8 x 1080p: 68 vs 61) -- and needs a few frames in flight, because a
   // frame's ticket word serialises at ~18 ns per tile (one 4K frame: 72 vs 35 us)
   const bool big_batch = g.n_frames >= 4 && g.total_tiles >= 24576;
-  a.compact_algo = force_algo ? force_algo : ctx->cfg.compact_algo ? ctx->cfg.compact_algo : (big_batch ? 2 : 1);
+  // camera-size launches whose tiles are all resident at once take ONE launch (k_compact_resident) unless the call
+  // is being captured (its epoch argument would freeze in the graph); one 1080p frame 16 -> ~8 us
+  const bool resident_ok = g.total_tiles <= uint32_t(ctx->cu_count * kResidentBlocksPerCu) && g.tiles_per_frame <= 1024u &&
+                           !capture_info(stream, nullptr);
+  const int dflt = big_batch ? 2 : resident_ok ? 3 : 1;
+  a.compact_algo = force_algo ? force_algo : ctx->cfg.compact_algo ? ctx->cfg.compact_algo : dflt;
+  if (a.compact_algo == 3 && !resident_ok) a.compact_algo = big_batch ? 2 : 1;  // (asked for, not possible here)
   if (a.compact_algo == 2) {
     // the single-pass kernel is software-pipelined over a block's tiles: it
     // wants few, long-lived blocks (about what is resident), not many short ones
@@ -450,6 +468,19 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     const uint32_t persistent = uint32_t(ctx->cu_count) * uint32_t(per_cu);
     a.grid = g.total_tiles < persistent ? g.total_tiles : persistent;
     if (a.grid < g.n_frames) a.compact_algo = 1;  // more frames than blocks: every block serves one frame only
+  }
+  if (a.compact_algo == 3) {
+    a.grid = g.total_tiles;
+    a.epoch = ctx->resident_epoch++;
+    if (ctx->resident_epoch >= kEpochEnd) {  // (once in 2^30 launches: start over from clean state)
+      ctx->resident_epoch = kEpochBase;
+      for (StateBuf *b : ctx->states.bufs)
+        if (b->p) {
+          if (b->pending) D2PC_HIP(ctx, hipEventSynchronize(b->done));
+          D2PC_HIP(ctx, hipMemsetAsync(b->p, 0, b->cap, nullptr));
+          D2PC_HIP(ctx, hipStreamSynchronize(nullptr));
+        }
+    }
   }
   if (a.compact_algo == 1) {  // (the two-pass grid is the default one computed above)
     uint32_t want2 = uint32_t(ctx->cu_count) * uint32_t(ctx->blocks_per_cu);
@@ -464,6 +495,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   if (st != D2PC_OK) return st;
   a.state = sb->p;
   sb->algo = a.compact_algo;
+  sb->epoch = a.epoch;
   D2PC_HIP(ctx, launch_compact(a));
   if (!sb->captured) {  // an event record inside a capture would become a graph node; a captured buffer is never shared
     D2PC_HIP(ctx, hipEventRecord(sb->done, stream));
@@ -633,7 +665,7 @@ int d2pc_create(const d2pc_config *cfg, d2pc_ctx **out) {
   if (cfg->struct_size != sizeof(d2pc_config)) return D2PC_ERR_INVALID_ARG;
   if (cfg->border < 0 || cfg->border > 16384) return D2PC_ERR_INVALID_ARG;
   if (cfg->mode != D2PC_MODE_PARITY && cfg->mode != D2PC_MODE_COMPACT) return D2PC_ERR_INVALID_ARG;
-  if (cfg->compact_algo < 0 || cfg->compact_algo > 2) return D2PC_ERR_INVALID_ARG;
+  if (cfg->compact_algo < 0 || cfg->compact_algo > 3) return D2PC_ERR_INVALID_ARG;
   if (std::isnan(cfg->min_disparity)) return D2PC_ERR_INVALID_ARG;
   int n = d2pc_device_count();
   if (n <= 0 || cfg->device_id < 0 || cfg->device_id >= n) return D2PC_ERR_NO_DEVICE;
@@ -654,6 +686,7 @@ int d2pc_create(const d2pc_config *cfg, d2pc_ctx **out) {
       hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), 65536 * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), sizeof(CompactStats)) != hipSuccess ||
       hipMemset(ctx->d_stats, 0, sizeof(CompactStats)) != hipSuccess ||
+      hipStreamSynchronize(nullptr) != hipSuccess ||  // (the fill may still be in flight when hipMemset returns)
       hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts), 65536 * sizeof(uint32_t), hipHostMallocDefault) !=
           hipSuccess) {
     d2pc_destroy(ctx);
@@ -928,10 +961,11 @@ int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scal
 // Reads the header of one state buffer whose last launch was the single pass.
 static int state_timed_out(d2pc_ctx *ctx, const StateBuf &b, bool *timed_out) {
   *timed_out = false;
-  if (!b.p || b.algo != 2) return D2PC_OK;  // the two-pass form has no in-launch hand-off and never reads the flag
+  if (!b.p || (b.algo != 2 && b.algo != 3)) return D2PC_OK;  // the two-pass form has no in-launch hand-off and never reads the flag
   StateHeader h;
   D2PC_HIP(ctx, hipMemcpy(&h, b.p, sizeof h, hipMemcpyDeviceToHost));
-  *timed_out = h.timeout != 0;
+  // single pass: its state clear zeroed the flag; resident blocks: nothing zeroes it, a give-up stores the launch's epoch
+  *timed_out = b.algo == 2 ? h.timeout != 0 : h.timeout == b.epoch;
   return D2PC_OK;
 }
 
@@ -978,6 +1012,7 @@ int d2pc_compact_stats_reset(d2pc_ctx *ctx) {
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
   D2PC_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(CompactStats)));
+  D2PC_HIP(ctx, hipStreamSynchronize(nullptr));
   ctx->n_twopass_fallbacks = 0;
   return D2PC_OK;
 }

@@ -115,6 +115,9 @@ struct CompactStats {
 constexpr uint32_t kCbTicketBytes = 128;
 constexpr uint32_t kCbMaxTilesX = 128;  // tiles per band: far below the blocks resident at once (3 per CU)
 __host__ __device__ inline uint32_t cb_band_acc_bytes(uint32_t tiles_y) { return (tiles_y * 8u + 127u) & ~127u; }
+// compact_algo 3 (k_compact_resident): the launch epochs its granules carry instead of being zeroed
+constexpr uint32_t kEpochBase = 1u << 30, kEpochEnd = 1u << 31;
+constexpr int kResidentBlocksPerCu = 4;  // what k_compact_resident's grid may be at most, per CU (<= 128 VGPRs: admitted)
 constexpr uint32_t kFrameTicketBytes = 256;   // the ticket word has a 256-B block to itself
 constexpr uint32_t kGroupAccStride = 128;     // one group accumulator per 128-B line
 constexpr uint64_t kGranuleTag = uint64_t(1) << 63;

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
       }
       if (x < x_end) {
         store_point<D2PC_STORE_NT != 0>(fout, row_point + x, X, Y, Z);
-        if (fidx) store_index(fidx, row_point + x, y * g.width + x);
+        if (fidx) st<D2PC_CB_INDEX_NT != 0>(fidx + (row_point + x), y * g.width + x);  // (nt: 647 -> 626 us with indices, 16 x 4K)
       }
     }
   }
@@ -893,6 +893,110 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t *__res
     tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, prefix, excl, wave, lane, g.roi_n);
     __syncthreads();
   }
+}
+
+// --------------------------------------------------------------------------
+// K2r: COMPACT for camera-size launches in ONE launch (compact_algo 3): one block per tile, every block RESIDENT.
+// The two-pass form costs a single frame two or three launches and two reads of the input (one 1080p frame 16 us
+// against 6.4 us PARITY); the persistent single pass serialises a lone frame on its ticket word.  Here every block
+// computes its tile once, publishes its survivor count as an 8-byte granule {epoch, count} and adds up the granules
+// of all tiles before it in the frame (<= 1023: all requested together), then scatters.
+//  * No zeroing launch: the granule carries the launch's EPOCH (a per-context counter in [2^30, 2^31): no count and no
+//    other kernel's state word looks like one), so whatever an earlier launch left in the buffer reads "not yet".
+//    An epoch is a kernel argument and freezes inside a captured graph: captures use the two-pass form.
+//  * No deadlock as long as the grid is resident at once (the host admits at most 4 blocks per CU: <= 128 VGPRs,
+//    hardly any LDS): a block waits only for blocks of the same launch, which are running.  Should the device
+//    be shared with something that keeps blocks from starting, the wait is bounded by time like the single pass's
+//    (0xFFFFFFFF in d_counts; the synchronous entry points rerun the frame with the two-pass form).
+// --------------------------------------------------------------------------
+template <int DT, int QK, int PXT, bool VEC>
+__global__ __launch_bounds__(kBlock) void k_compact_resident(const uint8_t *__restrict__ disp, float4 *__restrict__ out,
+                                                             uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
+                                                             uint8_t *state, CompactStats *stats, const Geom g, const QArg<QK> Q,
+                                                             const uint32_t epoch) {
+  using gu64 = __attribute__((address_space(1))) uint64_t;
+  constexpr int CELLS = PXT * (kBlock / 64);
+  __shared__ uint32_t s_cnt[CELLS];
+  __shared__ uint32_t s_prefix;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  D2PC_DECLARE_STRIPS(VEC, wave);
+  StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
+  const uint32_t t = blockIdx.x;
+  const uint32_t f = fdiv(t, g.div_tpf);
+  const uint32_t lt = t - f * g.tiles_per_frame;
+  const uint32_t base = lt * uint32_t(kBlock * PXT);
+  const FrameState fs(state, g, f);
+  TileRegs<DT, QK, PXT> r;
+  uint64_t mask[PXT];
+  tile_compute<DT, QK, PXT, VEC>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, base, wave, lane, wave_strip);
+  tile_ballots<DT, QK, PXT>(r, g, base, wave, lane, mask);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < PXT; ++k) s_cnt[cell_index(k, wave)] = uint32_t(__popcll(mask[k]));
+  }
+  __syncthreads();
+  uint32_t total;
+  const uint32_t excl = scan_cells<CELLS>(s_cnt, lane, total);
+  if (wave == 0) {
+    if (lane == 0)
+      __hip_atomic_store((gu64 *)(fs.granules + 2u * lt), (uint64_t(epoch) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t sum = 0, spins = 0;
+    uint64_t w0 = 0;
+    bool gave_up = false;
+    for (;;) {
+      bool ok = true;
+      sum = 0;
+      for (uint32_t i0 = 0; i0 < lt; i0 += 512u) {  // eight granules per lane and step, requested together
+        uint64_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t i = i0 + uint32_t(j) * 64u + lane;
+          v[j] = i < lt ? __hip_atomic_load((gu64 *)(fs.granules + 2u * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : (uint64_t(epoch) << 32);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ok = ok && uint32_t(v[j] >> 32) == epoch;
+          sum += uint32_t(v[j]);
+        }
+      }
+      if (__all(ok)) break;
+      if (spins == 0) w0 = __builtin_amdgcn_s_memrealtime();
+      backoff(spins);
+      ++spins;
+      if ((spins & 7u) == 0 && (__builtin_amdgcn_s_memrealtime() - w0 > uint64_t(g.spin_ticks) ||
+                                __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)) {
+        // the header's flag carries the epoch here (nothing zeroes it between launches)
+        if (lane == 0 && __hip_atomic_exchange(&hdr->timeout, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+          atomicAdd(&stats->timeouts, 1ull);
+        gave_up = true;
+        break;
+      }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) {
+      s_prefix = sum;
+      if (lt == g.tiles_per_frame - 1u)
+        __hip_atomic_store(counts + f, gave_up ? kCountTimedOut : sum + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (gave_up)
+        __hip_atomic_store(counts + f, kCountTimedOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if D2PC_ONEPASS_STATS
+      if (spins) {
+        CompactStats::Slot *sl = stats->slot + (blockIdx.x % uint32_t(kStatSlots));
+        atomicAdd(&sl->failed_polls, (unsigned long long)spins);
+        atomicAdd(&sl->wait_ticks, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - w0));
+      }
+      if (t == 0) {
+        atomicAdd(&stats->launches, 1ull);
+        atomicAdd(&stats->slot[0].tiles, (unsigned long long)g.total_tiles);
+      }
+#endif
+    }
+  }
+  __syncthreads();
+  float4 *fout = out + uint64_t(f) * g.out_frame_stride;
+  uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
+  tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, s_prefix, excl, wave, lane, g.roi_n);
 }
 
 // --------------------------------------------------------------------------
@@ -1858,6 +1962,10 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
       hipLaunchKernelGGL(k_compact_scan, dim3(a.geom.n_frames), dim3(kScanThreads), 0, a.stream, state, a.counts, a.geom);
     hipLaunchKernelGGL((k_compact_scatter<DT, QK, PXT, VEC>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, out,
                        a.out_index, a.counts, state, a.geom, make_qarg<QK>(a), selfscan);
+  } else if (a.compact_algo == 3) {  // one launch, one resident block per tile (the host checked the grid against the residency)
+    if (a.grid != a.geom.total_tiles || !a.stats || a.epoch < kEpochBase) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_compact_resident<DT, QK, PXT, VEC>), dim3(a.grid), dim3(kBlock), 0, a.stream, disp, out, a.out_index,
+                       a.counts, state, static_cast<CompactStats *>(a.stats), a.geom, make_qarg<QK>(a), a.epoch);
   } else {
     const uint32_t n16 = uint32_t((a.state_bytes + 15) / 16);  // buffers are allocated in whole MiB
 #if D2PC_CLEAR_WITH_MEMSET  // experiment only (tools/graph_memset_probe.py): round 1's hipMemsetAsync instead of the kernel

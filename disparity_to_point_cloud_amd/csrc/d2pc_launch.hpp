@@ -20,7 +20,8 @@ struct LaunchArgs {
   void *stats = nullptr;          // device: CompactStats of the context (single pass)
   int dtype = DT_F32;
   int pxt = 4;                    // ROI pixels per thread (tile = 256*pxt)
-  int compact_algo = 1;           // 1 two-pass, 2 single-pass
+  int compact_algo = 1;           // 1 two-pass, 2 single-pass, 3 one launch of resident blocks (k_compact_resident)
+  uint32_t epoch = 0;             // algo 3: this launch's epoch (kEpochBase <= epoch < kEpochEnd)
   bool parity_small = false;      // PARITY: one-shot blocks of 256 * pxt pixels (pxt 1, 2 or 4), k_reproject_pack_small
   bool vec_rows = false;          // fp32 rows fetchable 16 B per lane (alignment checked by the host)
   uint32_t grid = 1;

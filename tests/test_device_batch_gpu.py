@@ -110,7 +110,7 @@ def test_compact_is_idempotent_and_sorted_at_full_size():
     assert np.array_equal(roi, np.nonzero(keep)[0])
 
 
-@pytest.mark.parametrize("algo", [1, 2])  # count/scan/scatter nodes | memset + single-pass kernel nodes
+@pytest.mark.parametrize("algo", [1, 2, 3])  # count/scan/scatter nodes | memset + single-pass kernel nodes
 def test_launch_on_side_stream_and_graph_capture(algo):
     q = d2pc.make_q()
     frames = [synth_disparity(2, f, 640, 480, "holes") for f in range(6)]
@@ -146,7 +146,7 @@ def test_launch_on_side_stream_and_graph_capture(algo):
             assert_points_close(p1, wp, max_ulp=1)
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_two_streams_in_flight_from_one_context_do_not_share_compaction_state(algo):
     """Double buffering: COMPACT launches of ONE context enqueued on two streams overlap on the device.
     Each launch must own its tickets / partial counts / granules (round 1 shared one buffer: points came
@@ -348,3 +348,59 @@ def test_membench_kernels_fill_and_copy():
         assert torch.equal(buf[n:], src)
         with pytest.raises(d2pc.D2pcError):
             ctx.membench_copy(buf.data_ptr(), buf.data_ptr() + 16, n, s)   # overlap
+
+
+def test_resident_one_launch_compaction_over_many_relaunches_and_sizes():
+    """compact_algo 3 (k_compact_resident): one launch, epochs instead of a state clear.  Relaunched many times on one
+    state buffer (every launch must ignore what the previous ones published), on several sizes up to the residency
+    limit (beyond it the library falls back by itself); its launches are counted."""
+    q = d2pc.make_q()
+    for (w, h, n, kind) in ((752, 480, 1, "holes"), (1920, 1080, 1, "holes"), (1920, 1080, 1, "blocky"), (640, 480, 7, "holes"),
+                            (2000, 1100, 1, "holes"), (96, 96, 3, "holes"), (3840, 2160, 1, "holes")):
+        frames = [synth_disparity(3, 40 + f, w, h, kind) for f in range(n)]
+        want = [oracle.reproject_compact(fr, q, border=40) for fr in frames]
+        with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=3) as ctx:
+            b = _batch(ctx, frames, want_index=True)
+            for rep in range(8):
+                b.points.fill_(0)
+                b.counts.fill_(0)
+                b.launch()
+                res = b.results()
+                ctx.check_async_error()
+                for f, (pts, idx) in enumerate(res):
+                    assert np.array_equal(idx, want[f][1]), f"{w}x{h} rep {rep} frame {f}"
+                    assert_points_close(pts, want[f][0], max_ulp=1, what=f"{w}x{h} rep {rep} frame {f}")
+            st = ctx.compact_stats()
+            tiles = n * -(-d2pc.roi_points(w, h, 40) // 2048)
+            assert st["timeouts"] == 0 and st["launches"] == (8 if tiles <= 1024 else 0), (w, h, st)
+
+
+def test_resident_compaction_alternates_with_the_other_forms_on_one_state_buffer():
+    q = d2pc.make_q()
+    frames = [synth_disparity(3, 90 + f, 1280, 720, "holes") for f in range(2)]
+    want = [oracle.reproject_compact(fr, q, border=40) for fr in frames]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        b = _batch(ctx, frames, want_index=True)
+        L = d2pc.load_library()
+        for rep in range(9):
+            ctx._check(L.d2pc_set_tuning(ctx.handle, b"spin_timeout_ms", 2000))
+            cfg_algo = (3, 1, 2)[rep % 3]
+            # the context's algorithm is fixed at creation: drive the choice through a second context sharing nothing,
+            # except every third launch, which goes through THIS context's default (resident for this size)
+            if cfg_algo == 3:
+                b.points.fill_(0)
+                b.counts.fill_(0)
+                b.launch()
+                res = b.results()
+                ctx.check_async_error()
+            else:
+                with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=cfg_algo) as c2:
+                    b2 = _batch(c2, frames, want_index=True)
+                    b2.launch()
+                    res = b2.results()
+                    c2.check_async_error()
+            for f, (pts, idx) in enumerate(res):
+                assert np.array_equal(idx, want[f][1]), f"rep {rep} frame {f}"
+                assert_points_close(pts, want[f][0], max_ulp=1, what=f"rep {rep} frame {f}")
+        st = ctx.compact_stats()
+        assert st["launches"] == 3 and st["timeouts"] == 0

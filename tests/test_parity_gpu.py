@@ -214,7 +214,7 @@ def test_tile_shapes_agree_bitwise(q_default, pxt):
 
 
 # --------------------------------------------------------------- compact mode
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 @pytest.mark.parametrize("kind", ["holes", "blocky", "uniform"])
 def test_compact_vs_oracle_small(q_default, kind, algo):
     disp = synth_disparity(3, 0, 640, 360, kind)
@@ -228,7 +228,7 @@ def test_compact_vs_oracle_small(q_default, kind, algo):
     assert m.is_dense == 1 and m.width == len(gp)
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_c3_1080p_30pct_invalid(q_default, algo):
     """BASELINE.json configs[2]: 1920x1080 fp32, ~30 % invalid, compaction on."""
     for kind in ("holes", "blocky"):
@@ -242,7 +242,7 @@ def test_c3_1080p_30pct_invalid(q_default, algo):
         assert 0.6 < len(gp) / 1840000 < 0.8
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 @pytest.mark.parametrize("pxt", [4, 8, 16])
 def test_compact_edge_patterns(q_default, algo, pxt):
     rng = np.random.default_rng(99)
@@ -264,7 +264,7 @@ def test_compact_edge_patterns(q_default, algo, pxt):
             assert_points_close(gp, wp, max_ulp=MAX_ULP, what=name)
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_compact_tiny_w_takes_exact_slow_path(algo):
     """W so small that coordinates overflow float32 for part of the frame:
     the count pass's cheap predicate must fall back to the real arithmetic
