@@ -928,6 +928,8 @@ __global__ __launch_bounds__(kBlock) void k_compact_resident(const uint8_t *__re
   const FrameState fs(state, g, f);
   TileRegs<DT, QK, PXT> r;
   uint64_t mask[PXT];
+  // (Publishing the count from the cheap validity predicate BEFORE computing the points -- so that the arithmetic
+  // would run while the counts travel -- was slower: 9.6 -> 10.8 us at 752x480, 13.5 -> 14.3 us at 1080p.)
   tile_compute<DT, QK, PXT, VEC>(r, disp + uint64_t(f) * g.in_frame_stride, g, Q, base, wave, lane, wave_strip);
   tile_ballots<DT, QK, PXT>(r, g, base, wave, lane, mask);
   if (lane == 0) {
