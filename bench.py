@@ -617,16 +617,16 @@ def main():
                 c4.check_async_error()
                 rec[fused] = (sp, compaction_counters(c4))
             npts = int(b4.counts.sum().item())
-            kms, kms2 = rec[1][0]["median"], rec[0][0]["median"]
+            kms, kms2 = rec[2][0]["median"], rec[0][0]["median"]
             variants[f"callback_u8_median11_compact_30pct_zero_{hole_kind}"] = {
                 "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
-                "kernel_ms_spread": rec[1][0], "points_per_step": npts, "compaction_counters": rec[1][1],
-                "what": "d2pc_process_mono_device, COMPACT + indices: k_callback_bs_compact<11> (median of a tile, its "
-                        "surviving points in row-major order, row counts handed over inside the launch)",
+                "kernel_ms_spread": rec[2][0], "points_per_step": npts, "compaction_counters": rec[2][1],
+                "what": "d2pc_process_mono_device, COMPACT + indices: k_callback_bs_compact_pipe<11> (persistent blocks: median of "
+                        "a tile, then the previous tile's surviving points in row-major order; row counts handed over inside the launch)",
                 "as_two_launches_ms": kms2, "as_two_launches_ms_spread": rec[0][0],
                 "as_two_launches_what": "k_median_bs_u8<11> over the inset ROI + k_compact_onepass<U8>",
                 "speedup_over_two_launches": round(kms2 / kms, 3),
-                "pipelined_form_ms_spread": rec[2][0], "pipelined_form_counters": rec[2][1]}
+                "one_tile_per_block_form_ms_spread": rec[1][0], "one_tile_per_block_form_counters": rec[1][1]}
             del raw4
         del b4
         c4.close()
