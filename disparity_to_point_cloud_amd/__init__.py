@@ -17,6 +17,9 @@ from .capi import (  # noqa: F401
     DTYPE_MONO16,
     MODE_PARITY,
     MODE_COMPACT,
+    FORM_DEFAULT,
+    FORM_CV24,
+    FORM_CV4,
     CALIB_BLOB_BYTES,
     abi_version,
     calib_pack,

@@ -30,8 +30,9 @@ ABI_SYMBOLS = [
     "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16", "d2pc_last_stage_times",
     "d2pc_median_roi_device", "d2pc_host_alloc", "d2pc_host_free", "d2pc_make_q_flavour",
     "d2pc_process_mono_device", "d2pc_reserve_mono", "d2pc_release_graph_buffers", "d2pc_compact_stats",
-    "d2pc_compact_stats_reset", "d2pc_membench_fill", "d2pc_membench_copy",
+    "d2pc_compact_stats_reset", "d2pc_membench_fill", "d2pc_membench_copy", "d2pc_set_reproject_form",
 ]
+FORM_DEFAULT, FORM_CV24, FORM_CV4 = 0, 24, 4   # d2pc_reproject_form
 # d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
 (FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
  FUSE_ONLY_GOOD_AVG, FUSE_OVERLAP, FUSE_BLACK_TO_WHITE, FUSE_GRAD_FILTER) = range(9)
@@ -237,6 +238,7 @@ def load_library():
     L.d2pc_membench_fill.argtypes = [vp, vp, ctypes.c_size_t, vp]
     L.d2pc_membench_copy.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
     L.d2pc_set_tuning.argtypes = [vp, cp, ctypes.c_int]
+    L.d2pc_set_reproject_form.argtypes = [vp, ctypes.c_int]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int or fn.restype is None:
@@ -406,6 +408,10 @@ class Context:
         m = CloudMeta()
         self._check(self._L.d2pc_cloud_meta_fill(self._h, n_points, ctypes.byref(m)))
         return m
+
+    def set_reproject_form(self, form: int):
+        """FORM_DEFAULT / FORM_CV24 / FORM_CV4: which OpenCV generation's reprojectImageTo3D arithmetic (d2pc.h)."""
+        self._check(self._L.d2pc_set_reproject_form(self._h, form))
 
     def set_tuning(self, key: str, value: int):
         self._check(self._L.d2pc_set_tuning(self._h, key.encode(), value))

@@ -84,6 +84,11 @@ struct d2pc_ctx {
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
   int general_q_form = 0;        // 0: OpenCV 3/4's association bit for bit; 1: fused multiply-adds (round 2's form)
+  int reproject_form = 0;        // 0: per Q kind (specialised stereoRectify kernel / general kernel in OpenCV 3/4's form);
+                                 // 24: OpenCV 2.4's loop bit for bit (Q with exact column increments); 4: OpenCV 3/4's form for every Q
+  uint32_t qx_width = 0;         // reproject_form 24: columns the cached segment table below covers (0 = none)
+  uint32_t qx_n = 0, qx_x[kQxSegs] = {0};
+  double qx_c[kQxSegs] = {0};
   int no_vec_rows = 0;
   int stage_timing = 0;          // record per-stage HIP events in the synchronous host entry points
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -403,6 +408,56 @@ void free_pool(BufPool &pool) {
   pool.bufs.clear();
 }
 
+// Q for a launch over frames `width` columns wide: which kernel (specialised / general) and, for the general one, in
+// which arithmetic form (QMat::form); for OpenCV 2.4's form the table of its running column sum (cached per width).
+int fill_q(d2pc_ctx *ctx, LaunchArgs &a, int width) {
+  memcpy(a.q.q, ctx->q, sizeof a.q.q);
+  a.qs = ctx->qs;
+  a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
+  a.q.form = ctx->general_q_form == 1 ? 1u : 0u;
+  a.q.n_seg = 1;
+  a.q.pad = 0;
+  for (int j = 0; j < kQxSegs; ++j) a.q.seg_x[j] = 0, a.q.seg_c[j] = 0.0;
+  if (ctx->reproject_form == 4) {
+    a.q_kind = QK_GENERAL;
+    a.q.form = 0;
+  } else if (ctx->reproject_form == 24) {
+    const double *q = ctx->q;
+    auto pz = [](double x) { uint64_t b; memcpy(&b, &x, 8); return b == 0; };
+    if (!(q[0] == 1.0 && pz(q[1]) && pz(q[4]) && pz(q[8]) && pz(q[12])))
+      return fail(ctx, D2PC_ERR_INVALID_ARG,
+                  "reproject_form 24 (OpenCV 2.4's loop bit for bit) needs a Q whose column increments are exact "
+                  "(q00 = 1, q01 = q10 = q20 = q30 = +0, as cv::stereoRectify's): its x-recurrence has no parallel form otherwise");
+    if (ctx->qx_width < uint32_t(width)) {  // replay qx = q01*y + q03, then += q00 per column (one rounding per step)
+      volatile double s = 0.0 + q[3];       // (+0)*y = +0 for every row
+      uint32_t n = 1;
+      ctx->qx_x[0] = 0;
+      ctx->qx_c[0] = s;
+      const uint32_t cols = uint32_t(width) < 4096u ? 4096u : uint32_t(width);
+      for (uint32_t x = 1; x < cols; ++x) {
+        s = s + q[0];
+        const double c = s - double(x);
+        if (double(x) + c != s) return fail(ctx, D2PC_ERR_INTERNAL, "2.4-form column sum not representable as x + c at column %u", x);
+        if (c != ctx->qx_c[n - 1]) {
+          if (n == uint32_t(kQxSegs))
+            return fail(ctx, D2PC_ERR_BAD_SIZE, "reproject_form 24: the 2.4-form column sum changes its rounding more than %d times "
+                        "within %u columns for this principal point", kQxSegs, cols);
+          ctx->qx_x[n] = x;
+          ctx->qx_c[n] = c;
+          ++n;
+        }
+      }
+      ctx->qx_n = n;
+      ctx->qx_width = cols;
+    }
+    a.q_kind = QK_GENERAL;
+    a.q.form = 2;
+    a.q.n_seg = ctx->qx_n;
+    for (uint32_t j = 0; j < ctx->qx_n; ++j) a.q.seg_x[j] = ctx->qx_x[j], a.q.seg_c[j] = ctx->qx_c[j];
+  }
+  return D2PC_OK;
+}
+
 // bound on |u + cx|, |v + cy|, |f| over the frame, scaled by 2^-126: any |W| at least this large keeps every
 // quotient below 2^126 < FLT_MAX (QStereo::w_safe: the exact validity predicate of the COMPACT kernels)
 double w_safe_for(const d2pc_ctx *ctx, const Geom &g) {
@@ -423,10 +478,10 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   a.dtype = dtype;
   a.stream = stream;
   a.geom = g;
-  memcpy(a.q.q, ctx->q, sizeof a.q.q);
-  a.qs = ctx->qs;
-  a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
-  a.general_q_fma = ctx->general_q_form == 1;
+  {
+    int stq = fill_q(ctx, a, int(g.width));
+    if (stq != D2PC_OK) return stq;
+  }
   // 16-B row loads need every aligned group of four ROI pixels to sit in one
   // row at a 16-B aligned address
   a.vec_rows = !ctx->no_vec_rows && dtype == D2PC_DTYPE_F32 && g.roi_w % 4 == 0 && g.border % 4 == 0 &&
@@ -744,6 +799,7 @@ int d2pc_set_q(d2pc_ctx *ctx, const double q[16]) {
   if (!q) return fail(ctx, D2PC_ERR_INVALID_ARG, "q is null");
   memcpy(ctx->q, q, sizeof ctx->q);  // bit copy: keeps -0.0 in Q[3][3]
   ctx->have_q = true;
+  ctx->qx_width = 0;
   classify_q(ctx);
   return D2PC_OK;
 }
@@ -819,6 +875,7 @@ int d2pc_import_calibration(d2pc_ctx *ctx, const void *blob, size_t bytes) {
     return fail(ctx, D2PC_ERR_INVALID_ARG, "bad calibration blob (must be %d bytes with a valid border/mode)", D2PC_CALIB_BLOB_BYTES);
   memcpy(ctx->q, q, 128);
   ctx->have_q = true;
+  ctx->qx_width = 0;
   classify_q(ctx);
   ctx->cfg.border = border;
   ctx->cfg.mode = mode;
@@ -853,6 +910,14 @@ int d2pc_cloud_meta_fill(const d2pc_ctx *ctx, size_t n, d2pc_cloud_meta *m) {
   return D2PC_OK;
 }
 
+int d2pc_set_reproject_form(d2pc_ctx *ctx, int form) {
+  if (!ctx) return D2PC_ERR_INVALID_ARG;
+  if (form != D2PC_FORM_DEFAULT && form != D2PC_FORM_CV24 && form != D2PC_FORM_CV4)
+    return fail(ctx, D2PC_ERR_INVALID_ARG, "reproject form %d: not one of D2PC_FORM_*", form);
+  ctx->reproject_form = form;
+  return D2PC_OK;
+}
+
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   if (!ctx || !key) return D2PC_ERR_INVALID_ARG;
   if (!strcmp(key, "pxt_parity") && (value == 0 || value == 1 || value == 2 || tile_shape_supported(value))) ctx->pxt_parity = value;
@@ -862,6 +927,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 0 && value <= 64) ctx->onepass_blocks_per_cu = value;
   else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
   else if (!strcmp(key, "general_q_form") && (value == 0 || value == 1)) ctx->general_q_form = value;
+  else if (!strcmp(key, "reproject_form") && (value == 0 || value == 24 || value == 4)) ctx->reproject_form = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
@@ -1452,11 +1518,8 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
         a.counts = d_counts ? d_counts + f0 : nullptr;
         a.dtype = D2PC_DTYPE_U8;
         a.stream = sr;
-        memcpy(a.q.q, ctx->q, sizeof a.q.q);
-        a.qs = ctx->qs;
+        if ((st = fill_q(ctx, a, width)) != D2PC_OK) return st;
         a.qs.w_safe = w_safe_for(ctx, g);
-        a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
-        a.general_q_fma = ctx->general_q_form == 1;
         if (compact) {  // the COMPACT form hands row counts over between the tiles of a band: its own state
           uint32_t stride = 0;
           a.state_bytes = callback_compact_state_bytes((g.roi_w + 255u) / 256u, (g.roi_n / g.roi_w + 31u) / 32u, uint32_t(nf), &stride);

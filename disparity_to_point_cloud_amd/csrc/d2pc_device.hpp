@@ -59,12 +59,24 @@ struct Geom {
   uint32_t pxt;                       // ROI pixels per thread the tile counts above were formed with (host side)
 };
 
+constexpr int kQxSegs = 7;  // binades a 2.4-style running sum may cross inside one image row (2^9 .. 2^15 for |cx| < 512)
+
 // Q_ (reference hpp:72): row-major 4x4 doubles.  Kernarg => scalar registers,
 // i.e. one copy per wave with no LDS or vector-memory traffic at all.
 struct QMat {
   double q[16];
-  uint32_t fma_form;  // 0: OpenCV 3/4's association, bit for bit (default); 1: fused multiply-adds (tuning "general_q_form")
+  // how the general kernel evaluates (tuning "general_q_form" / "reproject_form"):
+  //   0  OpenCV 3/4's association, bit for bit (default)
+  //   1  fused multiply-adds (round 2's form)
+  //   2  OpenCV 2.4's loop, bit for bit -- for a Q whose column increments are exact (q00 = 1, q01 = q10 = q20 = q30 = +0,
+  //      as cv::stereoRectify's): 2.4 forms qx by adding q00 once per column, which rounds whenever the running sum
+  //      crosses a binade; the host replays that recurrence once per (Q, width) and hands over the <= kQxSegs segments
+  //      of columns in which qx - x is one constant
+  uint32_t form;
+  uint32_t n_seg;                 // form 2: segments in use (>= 1)
+  uint32_t seg_x[kQxSegs];        // segment j covers columns [seg_x[j], seg_x[j+1])   (seg_x[0] = 0)
   uint32_t pad;
+  double seg_c[kQxSegs];          // qx(u) = double(u) + seg_c[j], exactly
 };
 
 // The structure cv::stereoRectify always produces (hpp:104):

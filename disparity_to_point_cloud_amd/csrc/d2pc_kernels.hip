@@ -139,7 +139,7 @@ __device__ __forceinline__ void reproject(const QArg<QK_GENERAL> &A, uint32_t u,
                                           float &Y, float &Z) {
   const double *q = A.m.q;
   const double du = double(u), dv = double(v), dd = double(d);
-  if (A.m.fma_form) {  // (wave-uniform)
+  if (A.m.form == 1u) {  // (wave-uniform) round 2's fused multiply-adds
     const double nx = fma(q[2], dd, fma(q[0], du, fma(q[1], dv, q[3])));
     const double ny = fma(q[6], dd, fma(q[4], du, fma(q[5], dv, q[7])));
     const double nz = fma(q[10], dd, fma(q[8], du, fma(q[9], dv, q[11])));
@@ -148,6 +148,27 @@ __device__ __forceinline__ void reproject(const QArg<QK_GENERAL> &A, uint32_t u,
     X = float(nx * iw);
     Y = float(ny * iw);
     Z = big_z_rule(d, float(nz * iw));
+    return;
+  }
+  if (A.m.form == 2u) {
+    // OpenCV 2.4's loop (calib3d/calibration.cpp; oracle FORM_CV24), bit for bit, for a Q with exact column increments:
+    //   per row    qx = q01*y + q03, qy = q11*y + q13, qz = q21*y + q23, qw = q31*y + q33
+    //   per column iW = 1./(qw + q32*d); X = (qx + q02*d)*iW ...; then qx += q00, qy += q10, qz += q20, qw += q30
+    // q10 = q20 = q30 = +0 leave qy, qz, qw as the row formed them (but for a -0 there, which the first += turns
+    // into +0); qx is the running sum replayed by the host: column u lies in one of n_seg segments in which
+    // qx = u + seg_c[j] exactly.
+#pragma clang fp contract(off)
+    double c = A.m.seg_c[0];
+#pragma unroll
+    for (int j = 1; j < kQxSegs; ++j)
+      if (uint32_t(j) < A.m.n_seg && u >= A.m.seg_x[j]) c = A.m.seg_c[j];
+    const double qx = du + c;
+    double qy = q[5] * dv + q[7], qz = q[9] * dv + q[11], qw = q[13] * dv + q[15];
+    if (u != 0u) qy = qy + q[4], qz = qz + q[8], qw = qw + q[12];
+    const double iw = 1.0 / (qw + q[14] * dd);
+    X = float((qx + q[2] * dd) * iw);
+    Y = float((qy + q[6] * dd) * iw);
+    Z = big_z_rule(d, float((qz + q[10] * dd) * iw));
     return;
   }
   double h[4];
@@ -1899,9 +1920,7 @@ static QArg<QK> make_qarg(const LaunchArgs &a);
 template <>
 QArg<QK_GENERAL> make_qarg<QK_GENERAL>(const LaunchArgs &a) {
   QArg<QK_GENERAL> r;
-  r.m = a.q;
-  r.m.fma_form = a.general_q_fma ? 1u : 0u;
-  r.m.pad = 0;
+  r.m = a.q;  // (form and, for form 2, the segment table are filled by the host: d2pc_capi.hip)
   return r;
 }
 template <>

@@ -30,7 +30,6 @@ struct LaunchArgs {
   int q_kind = QK_GENERAL;        // QK_STEREO when Q has stereoRectify's structure
   QMat q{};
   QStereo qs{};
-  bool general_q_fma = false;     // general Q: round 2's fused multiply-add evaluation instead of OpenCV 4's association
 };
 
 // k x k median of 8-bit frames (d2pc_median.hip)

@@ -48,6 +48,7 @@ class Disparity2PCloudT {
   double cx_ = 376;
   double cy_ = 240;
   double base_line_ = 0.09;  // Omni-stereo
+  double reproject_form_ = 0;
   double Q_[16];             // hpp:72 (row-major 4x4)
   d2pc_ctx *ctx_ = nullptr;
   // DisparityImageCb's own calibration and context: Q and min_disparity come from each MESSAGE there, and
@@ -75,6 +76,9 @@ class Disparity2PCloudT {
     nh.param("cx_", cx_, 376);
     nh.param("cy_", cy_, 240);
     nh.param("base_line_", base_line_, 0.09);
+    // not in the reference: which OpenCV generation's reprojectImageTo3D arithmetic to reproduce bit for bit
+    // (0 = <= 1 ulp from both, 24 = OpenCV 2.4's loop, 4 = OpenCV 3/4's; d2pc_set_reproject_form)
+    nh.param("reproject_form", reproject_form_, 0);
     if (q_from_opencv) {
       for (int i = 0; i < 16; ++i) Q_[i] = q_from_opencv[i];
     } else if (d2pc_make_q_flavour(fx_, fy_, cx_, cy_, base_line_, 752, 480, D2PC_STEREORECTIFY_CV24, Q_) !=
@@ -90,6 +94,8 @@ class Disparity2PCloudT {
     if (st != D2PC_OK) throw std::runtime_error(std::string("d2pc_create: ") + d2pc_status_string(st));
     st = d2pc_set_q(ctx_, Q_);
     if (st != D2PC_OK) throw std::runtime_error(std::string("d2pc_set_q: ") + d2pc_status_string(st));
+    st = d2pc_set_reproject_form(ctx_, int(reproject_form_));
+    if (st != D2PC_OK) throw std::runtime_error(std::string("~reproject_form: ") + d2pc_last_error(ctx_));
     if (verbose_) d2pc_set_tuning(ctx_, "stage_timing", 1);  // the breadcrumbs below also say how long each stage took
   }
   ~Disparity2PCloudT() {
@@ -166,6 +172,7 @@ class Disparity2PCloudT {
       cfg.mode = mode_;
       const int st = d2pc_create(&cfg, &ctx_di_);
       if (st != D2PC_OK) throw std::runtime_error(std::string("d2pc_create (DisparityImage): ") + d2pc_status_string(st));
+      check_di(d2pc_set_reproject_form(ctx_di_, int(reproject_form_)), "~reproject_form");
     }
     bool same = have_q_di_;
     for (int i = 0; i < 16 && same; ++i) same = q[i] == Q_di_[i];

@@ -161,6 +161,29 @@ int d2pc_set_q(d2pc_ctx *ctx, const double q[16]);
 int d2pc_get_q(const d2pc_ctx *ctx, double q_out[16]);
 int d2pc_set_border(d2pc_ctx *ctx, int border);
 int d2pc_set_mode(d2pc_ctx *ctx, int mode);
+/* Which cv::reprojectImageTo3D (cpp:67) the points reproduce.  The two OpenCV
+ * generations evaluate the same Q*[x y d 1]^T in different orders and differ
+ * from each other by up to 1 float ulp (more where a numerator cancels):
+ *   D2PC_FORM_DEFAULT  cv::stereoRectify's Q: a specialised kernel, <= 1 ulp
+ *                      from BOTH generations (the exact quotient rounded once);
+ *                      any other Q: OpenCV 3/4's form bit for bit
+ *   D2PC_FORM_CV24     OpenCV 2.4's loop bit for bit (per row qx = q01*y + q03,
+ *                      then qx += q00 per column, one rounding per step).  That
+ *                      recurrence is sequential in x; it is reproduced in
+ *                      parallel only for a Q whose column steps are exact
+ *                      (q00 = 1, q01 = q10 = q20 = q30 = +0 -- what
+ *                      stereoRectify and d2pc_make_q* produce); any other Q
+ *                      makes the next call return D2PC_ERR_INVALID_ARG
+ *   D2PC_FORM_CV4      OpenCV 3/4's form bit for bit for every Q (Matx product
+ *                      left to right, numerators cast to float, times 1./W)
+ * The two exact forms run in double without contraction and cost arithmetic:
+ * profiles/r03_ab_forms.txt has them beside the default. */
+typedef enum d2pc_reproject_form {
+  D2PC_FORM_DEFAULT = 0,
+  D2PC_FORM_CV24 = 24,
+  D2PC_FORM_CV4 = 4
+} d2pc_reproject_form;
+int d2pc_set_reproject_form(d2pc_ctx *ctx, int form);
 /* COMPACT predicate threshold (e.g. DisparityImage.min_disparity): points with
  * d <= min_disparity are dropped; -inf disables it.  NaN is rejected. */
 int d2pc_set_min_disparity(d2pc_ctx *ctx, float min_disparity);
@@ -493,14 +516,18 @@ typedef struct d2pc_stage_times {
 int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
 
 /* Launch-shape tuning hook (no counterpart in the reference; results never
- * depend on it).  Keys: "pxt_parity" (ROI pixels per thread: 4, 8 or 16; 0 = choose per launch -- 4 up to
- * 32 Mpixel, 8 above), "pxt_compact" (4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by
+ * depend on it, but for the three keys that pick an arithmetic form: "reproject_form" = d2pc_set_reproject_form,
+ * "force_general_q" (0/1: a stereoRectify Q through the general kernel too) and "general_q_form" (0 = OpenCV 3/4's
+ * association, 1 = fused multiply-adds, kept for comparison).  Keys: "pxt_parity" (ROI pixels per thread: 1, 2 = one-shot blocks of 256 / 512 pixels, 4, 8 or 16 = tiles
+ * walked by a fixed grid; 0 = choose per launch: 2), "parity_small" (0/1/2: one-shot blocks off / also for 4 / default), "pxt_compact" (4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by
  * the tile count; 1..4096), "onepass_blocks_per_cu" (persistent blocks per CU of the single pass; 0 = choose:
  * 3 for 4K-class frames, 4 below), "force_general_q", "no_vec_rows", "fuse_rows" (rows per wave of
  * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
  * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
  * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
- * "callback_fused" (0/1, see d2pc_process_mono_device; default 1),
+ * "callback_fused" (0/1, see d2pc_process_mono_device; default 1), "callback_fused_compact" (COMPACT mode: 0 = two
+ * launches, 1 = one tile per block, 2 = persistent blocks that scatter one tile while filtering the next; default 2),
+ * "callback_pipe_blocks_per_cu" (1..8, default 3), "membench_blocks_per_cu" (d2pc_membench_*),
  * "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process / d2pc_process_mono8
  * without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose per launch,
  * 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes). */

@@ -121,6 +121,23 @@ def test_private_parameters_reach_the_calibration(replay, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", [24, 4])
+def test_private_parameter_reproject_form_gives_one_opencv_generation_bit_for_bit(replay, tmp_path, form):
+    """~reproject_form (not in the reference): the node as linked against OpenCV 2.4 / against 3-4, 0 ulp."""
+    import disparity_to_point_cloud_amd as d2pc
+
+    img = np.random.default_rng(form).integers(0, 256, size=(480, 752)).astype(np.uint8)
+    p, dst = _run(replay, "cloud", img, "mono8", tmp_path, f"reproject_form={form}")
+    assert p.returncode == 0, p.stderr
+    pts = np.frombuffer(dst.read_bytes().split(b"\n", 1)[1], dtype=np.float32).reshape(-1, 4)
+    q = d2pc.make_q_flavour(nx=752, ny=480)
+    want = oracle.reproject(oracle.median_u8(img, 11), q, border=40, scale=0.125,
+                            form=oracle.FORM_CV24 if form == 24 else oracle.FORM_CV4)
+    nan = np.isnan(want)
+    assert np.array_equal(nan, np.isnan(pts)) and np.array_equal(pts.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["padded_step", "bigendian", "padded_bigendian_hostmedian"])
 def test_mono16_message_layouts(replay, tmp_path, variant):
     """A little-endian mono16 message goes to the device raw (d2pc_process_mono16, any row step); a big-endian one

@@ -347,6 +347,44 @@ def test_tile_fused_callback_kernel_matches_the_two_launches_and_the_oracle(gene
         assert_points_close(pts[f][:len(want)], want, max_ulp=ulp, rel=1e-5, what=f"frame {f}")
 
 
+@pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
+@pytest.mark.parametrize("form,oform", [(24, oracle.FORM_CV24), (4, oracle.FORM_CV4)])
+def test_callback_body_in_one_opencv_generation_bit_for_bit(mode, form, oform):
+    """cpp:55-85 as a node linked against OpenCV 2.4 (form 24) or 3/4 (form 4) computes it: median, x 1/8, that
+    generation's reprojectImageTo3D arithmetic, ROI pack -- 0 ulp, one kernel and two launches."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    q = d2pc.make_q()
+    n, h, w = 2, 480, 752
+    imgs = np.random.default_rng(form).integers(0, 256, size=(n, h, w)).astype(np.uint8)
+    imgs[1, 100:300, 200:500] = 0
+    src = torch.from_numpy(imgs).cuda()
+    key = "callback_fused" if mode == d2pc.MODE_PARITY else "callback_fused_compact"
+    with d2pc.Context(q=q, border=40, mode=mode) as ctx:
+        ctx.set_tuning("reproject_form", form)
+        ctx.set_tuning("median_algo", 2)
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
+        for fused in (1, 0):
+            ctx.set_tuning(key, fused)
+            b.points.fill_(0); b.index.fill_(-1); b.counts.fill_(0)
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125, b.points.data_ptr(),
+                                    b.index.data_ptr(), b.stride, b.counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            pts, idx, cnt = b.points.cpu().numpy().reshape(n, -1, 4), b.index.cpu().numpy().view(np.uint32), b.counts.cpu().numpy()
+            for f in range(n):
+                filt = oracle.median_u8(imgs[f], 11)
+                if mode == d2pc.MODE_COMPACT:
+                    want, wi = oracle.reproject_compact(filt, q, border=40, scale=0.125, form=oform)
+                    assert np.array_equal(idx[f][:len(wi)], wi)
+                else:
+                    want = oracle.reproject(filt, q, border=40, scale=0.125, form=oform)
+                assert cnt[f] == len(want)
+                got = pts[f][:len(want)]
+                nan = np.isnan(want)
+                assert np.array_equal(nan, np.isnan(got))
+                assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan]), f"fused={fused} frame {f}"
+        ctx.check_async_error()
+
+
 @pytest.mark.parametrize("scale", [float("inf"), float("nan"), -0.125, 3.0e38, 0.0, 1e-45])
 def test_tile_fused_callback_kernel_with_degenerate_scales(scale):
     """The table of 1/W over the byte values must reproduce reproject()'s inf / NaN / signed-zero behaviour: byte 0

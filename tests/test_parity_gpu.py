@@ -314,6 +314,74 @@ def test_general_and_stereo_kernels_agree_bitwise(q_default):
     assert_points_close(a, want, max_ulp=MAX_ULP)
 
 
+def _same_bits(got, want, what=""):
+    nan = np.isnan(want)
+    assert np.array_equal(nan, np.isnan(got)), what + ": NaN pattern"
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan]), what
+
+
+@pytest.mark.parametrize("w,h,border,cx", [(752, 480, 40, 376.0), (3840, 2160, 40, 1919.5), (1025, 67, 0, 511.37),
+                                           (4099, 5, 1, 2050.123456789), (333, 200, 7, 0.1), (640, 360, 0, -3.75),
+                                           (65, 33, 0, 1e-9)])
+def test_reproject_form_selects_one_opencv_generation_bit_for_bit(w, h, border, cx):
+    """Tuning reproject_form: 24 = OpenCV 2.4's loop (running column sum qx += q00, replayed by the host into a table of
+    its roundings), 4 = OpenCV 3/4's Matx product with float numerators.  Each against the oracle's form of the same
+    name at 0 ulp on cv::stereoRectify's Q -- the calibrated path --, PARITY and COMPACT, with holes, NaN and inf in
+    the input.  (The default for that Q is the specialised kernel: <= 1 ulp from both, ~25 % less arithmetic.)"""
+    q = d2pc.make_q(cx=cx, cy=h / 2 - 0.3, nx=w, ny=h)
+    disp = synth_disparity(3, w + h, w, h, "holes")
+    disp[h // 2, w // 2 : w // 2 + 6] = [np.nan, np.inf, -np.inf, -1.0, 3.4028235e38, 1e-45][: min(6, w - w // 2)]
+    for form, oform in ((24, oracle.FORM_CV24), (4, oracle.FORM_CV4)):
+        with ctx_for(q, border=border) as ctx:
+            ctx.set_reproject_form(form)
+            _same_bits(ctx.process(disp), oracle.reproject(disp, q, border=border, form=oform), f"form {form} {w}x{h}")
+        wp, wi = oracle.reproject_compact(disp, q, border=border, form=oform)
+        for algo in (1, 2, 3):
+            with ctx_for(q, border=border, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+                ctx.set_tuning("reproject_form", form)
+                gp, gi = ctx.process(disp, want_index=True)
+            assert np.array_equal(gi, wi)
+            _same_bits(gp, wp, f"compact (algo {algo}) form {form} {w}x{h}")
+
+
+def test_reproject_form_24_u8_and_scale(q_default):
+    """The node's own input (uint8 disparities times 1/8, cpp:61) through OpenCV 2.4's form, bit for bit."""
+    rng = np.random.default_rng(24)
+    img = rng.integers(0, 256, size=(480, 752)).astype(np.uint8)
+    want = oracle.reproject(img, q_default, border=40, scale=0.125, form=oracle.FORM_CV24)
+    with ctx_for(q_default) as ctx:
+        ctx.set_tuning("reproject_form", 24)
+        _same_bits(ctx.process(img, scale=0.125), want, "u8 x 1/8, 2.4 form")
+    with ctx_for(q_default) as ctx:
+        base = ctx.process(img, scale=0.125)
+    assert_points_close(base, want, max_ulp=MAX_ULP, what="default kernel against the same frame")
+
+
+def test_reproject_form_24_refuses_a_q_without_exact_column_steps():
+    rng = np.random.default_rng(3)
+    q = rng.uniform(-1, 1, 16)
+    q[12:16] = [2e-4, 1e-4, 0.03, 0.7]
+    disp = np.ones((50, 60), dtype=np.float32)
+    with ctx_for(q, border=0) as ctx:
+        ctx.set_tuning("reproject_form", 24)
+        with pytest.raises(d2pc.D2pcError) as e:
+            ctx.process(disp)
+        assert e.value.status == 1 and "column" in str(e.value)
+        with pytest.raises(d2pc.D2pcError):
+            ctx.set_reproject_form(3)
+        ctx.set_reproject_form(d2pc.FORM_CV4)
+        got = ctx.process(disp)
+    assert np.array_equal(got.view(np.uint32), oracle.reproject(disp, q, border=0, form=oracle.FORM_CV4).view(np.uint32))
+    # a new Q on the same context drops the cached table of the old one
+    qa, qb = d2pc.make_q(cx=100.3), d2pc.make_q(cx=517.77)
+    disp = synth_disparity(3, 5, 700, 90, "k8")
+    with ctx_for(qa, border=0) as ctx:
+        ctx.set_tuning("reproject_form", 24)
+        _same_bits(ctx.process(disp), oracle.reproject(disp, qa, border=0), "first Q")
+        ctx.set_q(qb)
+        _same_bits(ctx.process(disp), oracle.reproject(disp, qb, border=0), "second Q")
+
+
 def test_compact_min_disparity(q_default):
     disp = synth_disparity(3, 3, 400, 300, "holes")
     wp, wi = oracle.reproject_compact(disp, q_default, border=40, min_disparity=64.0)
