@@ -215,6 +215,20 @@ def test_median_u8_against_numpy():
         assert np.array_equal(oracle.median_u8(img, k), ref)
 
 
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 11])
+def test_median_u8_against_scipy(k):
+    """An implementation nobody here wrote: scipy.ndimage.median_filter with replicated borders ('nearest' =
+    cv::BORDER_REPLICATE, what cv::medianBlur uses) on images smaller than, equal to and larger than the window,
+    with ties and constant regions."""
+    from scipy import ndimage
+    rng = np.random.default_rng(k)
+    for h, w in ((1, 1), (2, 9), (k, k), (k - 1, 3 * k), (64, 97), (131, 45)):
+        img = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+        if (h * w) % 2:
+            img = (img // 64 * 85).astype(np.uint8)
+        assert np.array_equal(oracle.median_u8(img, k), ndimage.median_filter(img, size=k, mode="nearest")), (h, w, k)
+
+
 # ---- depth-map fusion inner loop (SURVEY.md 8(f) #4) ---------------------------
 def test_fusion_rules_hand_derived():
     """Answers worked out by hand from the text of src/depth_map_fusion.cpp:162-235."""

@@ -47,7 +47,9 @@ for c in range(cases):
         frames = rng.integers(1, 65536, size=(n, h, w)).astype(np.uint16); scale = 1.0 / 64; tdt = torch.uint16
     frames[rng.random((n, h, w)) < holes] = 0
     m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
+    rform = int(rng.choice([0, 0, 24, 4])) if stereo else int(rng.choice([0, 4]))   # d2pc_set_reproject_form
     with d2pc.Context(q=q, border=border, mode=m, compact_algo=algo) as ctx:
+        ctx.set_reproject_form(rform)
         b = DeviceBatch(ctx, n, h, w, dtype=tdt, want_index=idx)
         b.disp.copy_(torch.from_numpy(frames.view(np.int16) if dt == "u16" else frames).view(tdt))
         b.launch(scale=scale)
@@ -57,8 +59,11 @@ for c in range(cases):
     # A general (dense) Q is evaluated in OpenCV 3/4's association: 0 ulp against the oracle's FORM_CV4 (round 2's fused
     # multiply-adds were up to 71 float ulp from the 2.4 form where a numerator cancels: that loosened bar is gone).
     # stereoRectify-structured Q: the specialised kernel, 1 ulp from the 2.4 form.
+    # An explicit form (24: OpenCV 2.4's loop, 4: OpenCV 3/4's) is that generation bit for bit, for stereoRectify's Q too.
     ulp, form = (1, oracle.FORM_CV24) if stereo else (0, oracle.FORM_CV4)
-    what = f"case {c}: n={n} {w}x{h} b={border} {dt} {mode} algo={algo} idx={idx} holes={holes} stereo={stereo}"
+    if rform:
+        ulp, form = 0, (oracle.FORM_CV24 if rform == 24 else oracle.FORM_CV4)
+    what = f"case {c}: n={n} {w}x{h} b={border} {dt} {mode} algo={algo} idx={idx} holes={holes} stereo={stereo} form={rform}"
     for f in range(n):
         if m == d2pc.MODE_PARITY:
             want = oracle.reproject(frames[f], q, border=border, scale=scale, form=form)

@@ -46,8 +46,10 @@ for c in range(cases):
         dt, rs = d2pc.DTYPE_U8, pitch
     res = {}
     forms = (2, 1, 0) if compact else (1, 0)
+    rform = int(rng.choice([0, 0, 24, 4]))   # d2pc_set_reproject_form: one OpenCV generation bit for bit
     with d2pc.Context(q=q, border=border, mode=d2pc.MODE_COMPACT if compact else d2pc.MODE_PARITY) as ctx:
         ctx.set_tuning("force_general_q", general)
+        ctx.set_reproject_form(rform)
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=want_idx)
         s = torch.cuda.current_stream().cuda_stream
@@ -60,11 +62,13 @@ for c in range(cases):
             torch.cuda.synchronize()
             res[fused] = [b.points.cpu().numpy().copy(), b.counts.cpu().numpy().copy()] + ([b.index.cpu().numpy().copy()] if want_idx else [])
         ctx.check_async_error()
-    what = f"case {c}: k={k} {w}x{h} n={n} border={border} scale={scale} mono16={mono16} idx={want_idx} general={general} compact={compact} holes={holes}"
+    what = f"case {c}: k={k} {w}x{h} n={n} border={border} scale={scale} mono16={mono16} idx={want_idx} general={general} compact={compact} holes={holes} form={rform}"
     for fused in forms[:-1]:
         for x, y in zip(res[fused], res[0]):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), what + f": fused form {fused} != two launches"
     form, ulp = (oracle.FORM_CV4, 0) if general else (oracle.FORM_CV24, 1)   # a general Q is OpenCV 4's association bit for bit
+    if rform:
+        form, ulp = (oracle.FORM_CV24 if rform == 24 else oracle.FORM_CV4), 0
     for f in range(n):
         filt = oracle.median_u8(m8[f], k)
         if compact:
