@@ -335,10 +335,29 @@ inline int run(const Options &o) {
   unsigned char blob0[D2PC_CALIB_BLOB_BYTES];
   if (d2pc_calib_pack(q, 40, o.compact ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, blob0) != D2PC_OK) return 2;
 
-  std::vector<ncclComm_t> comms(size_t(n), nullptr);
-  std::vector<hipStream_t> streams(size_t(n), nullptr);
-  std::vector<unsigned char *> d_blob(size_t(n), nullptr);
-  std::vector<unsigned long long *> d_cnt(size_t(n), nullptr);
+  // everything the collectives own, released on every way out of this function
+  struct Resources {
+    const Options &o;
+    Rccl &rccl;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;
+    std::vector<unsigned char *> d_blob;
+    std::vector<unsigned long long *> d_cnt;
+    Resources(const Options &opt, Rccl &r, size_t n) : o(opt), rccl(r), comms(n, nullptr), streams(n, nullptr), d_blob(n, nullptr), d_cnt(n, nullptr) {}
+    ~Resources() {
+      for (size_t r = 0; r < comms.size(); ++r) {
+        (void)hipSetDevice(o.devices[r]);
+        if (d_blob[r]) (void)hipFree(d_blob[r]);
+        if (d_cnt[r]) (void)hipFree(d_cnt[r]);
+        if (streams[r]) (void)hipStreamDestroy(streams[r]);
+        if (comms[r]) (void)rccl.CommDestroy(comms[r]);
+      }
+    }
+  } res(o, rccl, size_t(n));
+  std::vector<ncclComm_t> &comms = res.comms;
+  std::vector<hipStream_t> &streams = res.streams;
+  std::vector<unsigned char *> &d_blob = res.d_blob;
+  std::vector<unsigned long long *> &d_cnt = res.d_cnt;
   D2PC_MULTI_NCCL(rccl.CommInitAll(comms.data(), n, o.devices.data()));
   for (int r = 0; r < n; ++r) {
     D2PC_MULTI_HIP(hipSetDevice(o.devices[size_t(r)]));
@@ -348,6 +367,9 @@ inline int run(const Options &o) {
     // only the root's buffer holds the calibration; every other device starts from a poison pattern
     if (r == 0) D2PC_MULTI_HIP(hipMemcpy(d_blob[0], blob0, sizeof blob0, hipMemcpyHostToDevice));
     else D2PC_MULTI_HIP(hipMemset(d_blob[size_t(r)], 0xEE, D2PC_CALIB_BLOB_BYTES));
+    // hipMemset of device memory and hipMemcpy from pageable memory may return before the device has the bytes, and
+    // the collectives' streams are non-blocking (they do not wait for the NULL stream): drain the device first
+    D2PC_MULTI_HIP(hipDeviceSynchronize());
   }
   // C1: the 136-byte blob from rank 0 into every device's memory, over xGMI
   D2PC_MULTI_NCCL(rccl.GroupStart());
@@ -386,6 +408,7 @@ inline int run(const Options &o) {
   for (int r = 0; r < n; ++r) {
     D2PC_MULTI_HIP(hipSetDevice(o.devices[size_t(r)]));
     D2PC_MULTI_HIP(hipMemcpy(d_cnt[size_t(r)], results[size_t(r)].counters, sizeof results[size_t(r)].counters, hipMemcpyHostToDevice));
+    D2PC_MULTI_HIP(hipDeviceSynchronize());  // (as above: the all-reduce runs on a non-blocking stream)
   }
   D2PC_MULTI_NCCL(rccl.GroupStart());
   for (int r = 0; r < n; ++r) {
@@ -414,13 +437,6 @@ inline int run(const Options &o) {
          o.encoding.c_str(), o.median, o.compact ? "compact" : "parity", o.depth);
   for (int r = 0; r < n; ++r) printf("%s%llu", r ? ", " : "", results[size_t(r)].counters[0]);
   printf("]}\n");
-  for (int r = 0; r < n; ++r) {
-    (void)hipSetDevice(o.devices[size_t(r)]);
-    (void)hipFree(d_blob[size_t(r)]);
-    (void)hipFree(d_cnt[size_t(r)]);
-    (void)hipStreamDestroy(streams[size_t(r)]);
-    (void)rccl.CommDestroy(comms[size_t(r)]);
-  }
   return failed ? 8 : 0;
 }
 

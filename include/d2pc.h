@@ -75,10 +75,14 @@ typedef struct d2pc_config {
   int32_t border;         /* ROI inset on all four sides; cpp:70,72 => 40     */
   int32_t mode;           /* d2pc_mode                                        */
   float min_disparity;    /* COMPACT only: also drop d <= this; -inf = off    */
-  int32_t compact_algo;   /* 0 = library default (single pass for launches of
-                             >= 4 frames and >= ~25k tiles, two-pass below);
+  int32_t compact_algo;   /* 0 = library default: single pass (2) for launches
+                             of >= 4 frames and >= ~25k tiles; one resident
+                             launch (3) when every tile of the launch fits on
+                             the device at once (camera-size frames) and the
+                             call is not being captured; two-pass (1) else.
                              1 = two-pass count/scan/scatter; 2 = single-pass
-                             counted hand-off                                 */
+                             counted hand-off; 3 = one block per tile, all
+                             resident (falls back to 1 / 2 where impossible) */
   int32_t reserved[4];
 } d2pc_config;
 
