@@ -497,14 +497,18 @@ def main():
     if rank == 0 and world == 1 and not a.no_variants:  # side measurements only in the 1-GPU run
         variants = {}
         n_side = max(a.steps // 4, 5)  # launches per round; rounds repeat until >= 100 ms (timed_rounds)
-        for name, vmode, vborder, kind, idx in (
-            ("parity_border0", d2pc.MODE_PARITY, 0, "uniform", False),
-            ("compact_border40_all_valid", d2pc.MODE_COMPACT, 40, "uniform", False),
-            ("compact_border40_30pct_holes", d2pc.MODE_COMPACT, 40, "holes", False),
-            ("compact_border40_30pct_holes_index", d2pc.MODE_COMPACT, 40, "holes", True),
-            ("compact_border40_all_valid_index", d2pc.MODE_COMPACT, 40, "uniform", True),
+        for name, vmode, vborder, kind, idx, form in (
+            ("parity_border0", d2pc.MODE_PARITY, 0, "uniform", False, d2pc.FORM_DEFAULT),
+            ("compact_border40_all_valid", d2pc.MODE_COMPACT, 40, "uniform", False, d2pc.FORM_DEFAULT),
+            ("compact_border40_30pct_holes", d2pc.MODE_COMPACT, 40, "holes", False, d2pc.FORM_DEFAULT),
+            ("compact_border40_30pct_holes_index", d2pc.MODE_COMPACT, 40, "holes", True, d2pc.FORM_DEFAULT),
+            ("compact_border40_all_valid_index", d2pc.MODE_COMPACT, 40, "uniform", True, d2pc.FORM_DEFAULT),
+            # the headline workload with one OpenCV generation's arithmetic reproduced bit for bit (d2pc_set_reproject_form)
+            ("parity_border40_opencv24_bit_for_bit", d2pc.MODE_PARITY, 40, "uniform", False, d2pc.FORM_CV24),
+            ("parity_border40_opencv4_bit_for_bit", d2pc.MODE_PARITY, 40, "uniform", False, d2pc.FORM_CV4),
         ):
             c2 = d2pc.Context(device_id=local_rank, border=vborder, mode=vmode, q=q)
+            c2.set_reproject_form(form)
             b2 = DeviceBatch(c2, a.frames, H4K, W4K, want_index=idx, device=dev)
             if kind == "uniform":
                 b2.disp.copy_(batch.disp)

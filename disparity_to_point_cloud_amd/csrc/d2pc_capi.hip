@@ -87,8 +87,7 @@ struct d2pc_ctx {
   int reproject_form = 0;        // 0: per Q kind (specialised stereoRectify kernel / general kernel in OpenCV 3/4's form);
                                  // 24: OpenCV 2.4's loop bit for bit (Q with exact column increments); 4: OpenCV 3/4's form for every Q
   uint32_t qx_width = 0;         // reproject_form 24: columns the cached segment table below covers (0 = none)
-  uint32_t qx_n = 0, qx_x[kQxSegs] = {0};
-  double qx_c[kQxSegs] = {0};
+  QxSegs qx_seg{};
   int no_vec_rows = 0;
   int stage_timing = 0;          // record per-stage HIP events in the synchronous host entry points
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -415,45 +414,58 @@ int fill_q(d2pc_ctx *ctx, LaunchArgs &a, int width) {
   a.qs = ctx->qs;
   a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
   a.q.form = ctx->general_q_form == 1 ? 1u : 0u;
-  a.q.n_seg = 1;
-  a.q.pad = 0;
-  for (int j = 0; j < kQxSegs; ++j) a.q.seg_x[j] = 0, a.q.seg_c[j] = 0.0;
+  a.q.seg = QxSegs{};
+  a.q.seg.n = 1;
+  if (ctx->reproject_form == 0) return D2PC_OK;
+  // One OpenCV generation bit for bit.  cv::stereoRectify's Q keeps specialised kernels (QK_STEREO_CV24 / _CV4: the
+  // generation's roundings of W and of the numerators, d2pc_device.hpp); any other Q -- and tuning
+  // "force_general_q", which lets the tests compare the two routes -- goes through the general kernel.
+  const bool stereo = a.q_kind == QK_STEREO;
   if (ctx->reproject_form == 4) {
-    a.q_kind = QK_GENERAL;
-    a.q.form = 0;
-  } else if (ctx->reproject_form == 24) {
-    const double *q = ctx->q;
-    auto pz = [](double x) { uint64_t b; memcpy(&b, &x, 8); return b == 0; };
-    if (!(q[0] == 1.0 && pz(q[1]) && pz(q[4]) && pz(q[8]) && pz(q[12])))
-      return fail(ctx, D2PC_ERR_INVALID_ARG,
-                  "reproject_form 24 (OpenCV 2.4's loop bit for bit) needs a Q whose column increments are exact "
-                  "(q00 = 1, q01 = q10 = q20 = q30 = +0, as cv::stereoRectify's): its x-recurrence has no parallel form otherwise");
-    if (ctx->qx_width < uint32_t(width)) {  // replay qx = q01*y + q03, then += q00 per column (one rounding per step)
-      volatile double s = 0.0 + q[3];       // (+0)*y = +0 for every row
-      uint32_t n = 1;
-      ctx->qx_x[0] = 0;
-      ctx->qx_c[0] = s;
-      const uint32_t cols = uint32_t(width) < 4096u ? 4096u : uint32_t(width);
-      for (uint32_t x = 1; x < cols; ++x) {
-        s = s + q[0];
-        const double c = s - double(x);
-        if (double(x) + c != s) return fail(ctx, D2PC_ERR_INTERNAL, "2.4-form column sum not representable as x + c at column %u", x);
-        if (c != ctx->qx_c[n - 1]) {
-          if (n == uint32_t(kQxSegs))
-            return fail(ctx, D2PC_ERR_BAD_SIZE, "reproject_form 24: the 2.4-form column sum changes its rounding more than %d times "
-                        "within %u columns for this principal point", kQxSegs, cols);
-          ctx->qx_x[n] = x;
-          ctx->qx_c[n] = c;
-          ++n;
-        }
-      }
-      ctx->qx_n = n;
-      ctx->qx_width = cols;
+    if (stereo) {
+      a.q_kind = QK_STEREO_CV4;
+      a.qs.f = double(float(a.qs.f));  // Vec3f p = Vec3d(h.val): Z's numerator is the float of f
+    } else {
+      a.q_kind = QK_GENERAL;
+      a.q.form = 0;
     }
+    return D2PC_OK;
+  }
+  const double *q = ctx->q;
+  auto pz = [](double x) { uint64_t b; memcpy(&b, &x, 8); return b == 0; };
+  if (!(q[0] == 1.0 && pz(q[1]) && pz(q[4]) && pz(q[8]) && pz(q[12])))
+    return fail(ctx, D2PC_ERR_INVALID_ARG,
+                "reproject_form 24 (OpenCV 2.4's loop bit for bit) needs a Q whose column increments are exact "
+                "(q00 = 1, q01 = q10 = q20 = q30 = +0, as cv::stereoRectify's): its x-recurrence has no parallel form otherwise");
+  if (ctx->qx_width < uint32_t(width)) {  // replay qx = q01*y + q03, then += q00 per column (one rounding per step)
+    volatile double s = 0.0 + q[3];       // (+0)*y = +0 for every row
+    QxSegs sg{};
+    sg.n = 1;
+    sg.x[0] = 0;
+    sg.c[0] = s;
+    const uint32_t cols = uint32_t(width) < 4096u ? 4096u : uint32_t(width);
+    for (uint32_t x = 1; x < cols; ++x) {
+      s = s + q[0];
+      const double c = s - double(x);
+      if (double(x) + c != s) return fail(ctx, D2PC_ERR_INTERNAL, "2.4-form column sum not representable as x + c at column %u", x);
+      if (c != sg.c[sg.n - 1]) {
+        if (sg.n == uint32_t(kQxSegs))
+          return fail(ctx, D2PC_ERR_BAD_SIZE, "reproject_form 24: the 2.4-form column sum changes its rounding more than %d times "
+                      "within %u columns for this principal point", kQxSegs, cols);
+        sg.x[sg.n] = x;
+        sg.c[sg.n] = c;
+        ++sg.n;
+      }
+    }
+    ctx->qx_seg = sg;
+    ctx->qx_width = cols;
+  }
+  a.q.seg = ctx->qx_seg;
+  if (stereo) {
+    a.q_kind = QK_STEREO_CV24;
+  } else {
     a.q_kind = QK_GENERAL;
     a.q.form = 2;
-    a.q.n_seg = ctx->qx_n;
-    for (uint32_t j = 0; j < ctx->qx_n; ++j) a.q.seg_x[j] = ctx->qx_x[j], a.q.seg_c[j] = ctx->qx_c[j];
   }
   return D2PC_OK;
 }

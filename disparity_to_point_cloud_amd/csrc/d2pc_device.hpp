@@ -61,6 +61,14 @@ struct Geom {
 
 constexpr int kQxSegs = 7;  // binades a 2.4-style running sum may cross inside one image row (2^9 .. 2^15 for |cx| < 512)
 
+// OpenCV 2.4's running column sum qx (per row qx = q01*y + q03, then qx += q00 per column, one rounding per step)
+// as the host replayed it for one (Q, width): columns [x[j], x[j+1]) have qx(u) = double(u) + c[j] EXACTLY.
+struct QxSegs {
+  uint32_t n;           // segments in use (>= 1)
+  uint32_t x[kQxSegs];  // x[0] = 0
+  double c[kQxSegs];
+};
+
 // Q_ (reference hpp:72): row-major 4x4 doubles.  Kernarg => scalar registers,
 // i.e. one copy per wave with no LDS or vector-memory traffic at all.
 struct QMat {
@@ -73,23 +81,31 @@ struct QMat {
   //      crosses a binade; the host replays that recurrence once per (Q, width) and hands over the <= kQxSegs segments
   //      of columns in which qx - x is one constant
   uint32_t form;
-  uint32_t n_seg;                 // form 2: segments in use (>= 1)
-  uint32_t seg_x[kQxSegs];        // segment j covers columns [seg_x[j], seg_x[j+1])   (seg_x[0] = 0)
-  uint32_t pad;
-  double seg_c[kQxSegs];          // qx(u) = double(u) + seg_c[j], exactly
+  QxSegs seg;                     // form 2
 };
 
 // The structure cv::stereoRectify always produces (hpp:104):
 //   [1 0 0 cx; 0 1 0 cy; 0 0 0 f; 0 0 a b]   (zeros are +0.0, ones are 1.0)
 // lets the kernel drop nine multiply-adds per pixel with bit-identical
 // results: X = (u + cx)/W, Y = (v + cy)/W, Z = f/W, W = a*d + b.
+//
+// One OpenCV generation bit for bit (d2pc_set_reproject_form) costs this structure little.  With the zeros and ones
+// above, either generation's evaluation collapses to W = b + RN(a*d) (product and sum rounded apart, where the default
+// kind fuses them), and
+//   QK_STEREO_CV24  (2.4)  X = qx(u)*iW with the running column sum qx of QxSegs, Y = (v + cy)*iW, Z = f*iW
+//   QK_STEREO_CV4   (3/4)  the numerators pass through float: X = float(u + cx)*ia, Y = float(v + cy)*ia,
+//                          Z = float(f)*ia (f arrives already rounded to float from the host)
+// They are kernel KINDS (template instances), not a run-time switch: the default kind's kernels -- short of scalar
+// registers as they are -- stay exactly as they were.  Derivation: DESIGN.md section 2; each is checked bit for bit
+// against the general kernel in the same form and against the oracle.
 struct QStereo {
   double cx, cy, f, a, b;  // cx = q03 + 0.0, cy = q13 + 0.0, f = q23 + 0.0, b = q33 + 0.0
   double w_safe;           // |W| >= w_safe  =>  every coordinate is a finite float (per launch)
 };
 
 enum : int { DT_F32 = 0, DT_U8 = 1, DT_U16 = 2 };
-enum : int { QK_GENERAL = 0, QK_STEREO = 1 };
+enum : int { QK_GENERAL = 0, QK_STEREO = 1, QK_STEREO_CV24 = 2, QK_STEREO_CV4 = 3 };
+constexpr bool is_stereo(int qk) { return qk != QK_GENERAL; }
 
 // ---- compaction state (zeroed by a memset node before every launch) -------
 //   [StateHeader 128 B][frame 0 state][frame 1 state]...

@@ -121,6 +121,24 @@ template <>
 struct QArg<QK_STEREO> {
   QStereo s;
 };
+template <>
+struct QArg<QK_STEREO_CV24> {
+  QStereo s;
+  QxSegs seg;
+};
+template <>
+struct QArg<QK_STEREO_CV4> {
+  QStereo s;
+};
+
+// c with qx(u) = double(u) + c for OpenCV 2.4's running column sum (QxSegs): the segment column u lies in.
+__device__ __forceinline__ double qx_offset(const QxSegs &sg, uint32_t u) {
+  double c = sg.c[0];
+#pragma unroll
+  for (int j = 1; j < kQxSegs; ++j)
+    if (uint32_t(j) < sg.n && u >= sg.x[j]) c = sg.c[j];
+  return c;
+}
 
 // cv::reprojectImageTo3D ends every pixel with `if (fabs(d - minDisparity) <= FLT_EPSILON) Z = bigZ`
 // (bigZ = 10000); with handleMissingValues = false (cpp:64) minDisparity stays FLT_MAX, so the test
@@ -158,11 +176,7 @@ __device__ __forceinline__ void reproject(const QArg<QK_GENERAL> &A, uint32_t u,
     // into +0); qx is the running sum replayed by the host: column u lies in one of n_seg segments in which
     // qx = u + seg_c[j] exactly.
 #pragma clang fp contract(off)
-    double c = A.m.seg_c[0];
-#pragma unroll
-    for (int j = 1; j < kQxSegs; ++j)
-      if (uint32_t(j) < A.m.n_seg && u >= A.m.seg_x[j]) c = A.m.seg_c[j];
-    const double qx = du + c;
+    const double qx = du + qx_offset(A.m.seg, u);
     double qy = q[5] * dv + q[7], qz = q[9] * dv + q[11], qw = q[13] * dv + q[15];
     if (u != 0u) qy = qy + q[4], qz = qz + q[8], qw = qw + q[12];
     const double iw = 1.0 / (qw + q[14] * dd);
@@ -190,13 +204,42 @@ __device__ __forceinline__ void reproject(const QArg<QK_GENERAL> &A, uint32_t u,
 // products with +0.0 and 1.0 are exact, so only the sums that can round
 // remain.  A non-finite d makes every coordinate NaN in the general form
 // (0*inf), reproduced here by poisoning d before W is formed.
-__device__ __forceinline__ void reproject(const QArg<QK_STEREO> &A, uint32_t u, uint32_t v, float d, float &X,
-                                          float &Y, float &Z) {
+//
+// W and the numerators of the kind's OpenCV generation (d2pc_device.hpp).
+template <int QK>
+__device__ __forceinline__ double stereo_w(const QArg<QK> &A, double dd) {
+  if constexpr (is_stereo(QK)) {
+    return fma(A.s.a, dd, A.s.b);
+  } else {
+#pragma clang fp contract(off)
+    const double t = A.s.a * dd;  // both generations round the product and the sum apart
+    return A.s.b + t;
+  }
+}
+template <int QK>
+__device__ __forceinline__ double stereo_nx(const QArg<QK> &A, uint32_t u) {
+  const double du = double(u);
+  if constexpr (QK == QK_STEREO_CV24) {
+    return du + qx_offset(A.seg, u);
+  } else {
+    const double n = du + A.s.cx;
+    if constexpr (QK == QK_STEREO_CV4) return double(float(n));
+    return n;
+  }
+}
+template <int QK>
+__device__ __forceinline__ double stereo_ny(const QArg<QK> &A, uint32_t v) {
+  const double n = double(v) + A.s.cy;
+  if constexpr (QK == QK_STEREO_CV4) return double(float(n));
+  return n;
+}
+template <int QK, typename std::enable_if<is_stereo(QK), int>::type = 0>
+__device__ __forceinline__ void reproject(const QArg<QK> &A, uint32_t u, uint32_t v, float d, float &X, float &Y, float &Z) {
   const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
-  const double nw = fma(A.s.a, double(dsel), A.s.b);
+  const double nw = stereo_w(A, double(dsel));
   const double iw = 1.0 / nw;
-  X = float((double(u) + A.s.cx) * iw);
-  Y = float((double(v) + A.s.cy) * iw);
+  X = float(stereo_nx(A, u) * iw);
+  Y = float(stereo_ny(A, v) * iw);
   Z = big_z_rule(d, float(A.s.f * iw));
 }
 
@@ -233,10 +276,11 @@ __device__ __forceinline__ void store_index(uint32_t *frame_idx, uint32_t point,
 //   W == 0 or NaN  =>  iW is inf/NaN, Z = f*iW is not finite -> invalid
 //   0 < |W| < w_safe (never seen with real calibrations): evaluate fully.
 // w_safe = 2^-126 * max|numerator| is formed on the host (QStereo::w_safe).
-__device__ __forceinline__ bool stereo_point_valid(const QArg<QK_STEREO> &A, uint32_t u, uint32_t v, float d,
+template <int QK>
+__device__ __forceinline__ bool stereo_point_valid(const QArg<QK> &A, uint32_t u, uint32_t v, float d,
                                                    float min_disparity) {
   const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
-  const double nw = fma(A.s.a, double(dsel), A.s.b);
+  const double nw = stereo_w(A, double(dsel));
   const double aw = fabs(nw);
   bool ok = aw >= A.s.w_safe;  // false for NaN
   if (!ok && aw > 0.0) {       // tiny non-zero W: decide by the real arithmetic
@@ -486,10 +530,10 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
   double *lut_iw = reinterpret_cast<double *>(s_raw);              // [256]
   float *lut_z = reinterpret_cast<float *>(s_raw) + 2 * 256;       // [256]
   static_assert(S::RAW_WORDS >= 3 * 256, "the table fits where the staged rows were");
-  if constexpr (QK == QK_STEREO) {
+  if constexpr (is_stereo(QK)) {
     const float d = __fmul_rn(float(tid), g.scale);  // cpp:61, as load_disparity<DT_U8>
     const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
-    const double iw = 1.0 / fma(Q.s.a, double(dsel), Q.s.b);
+    const double iw = 1.0 / stereo_w(Q, double(dsel));
     lut_iw[tid] = iw;
     lut_z[tid] = big_z_rule(d, float(Q.s.f * iw));
     __syncthreads();
@@ -503,7 +547,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     xs[q] = 0.0;
-    if constexpr (QK == QK_STEREO) xs[q] = double(x0 + 64u * uint32_t(q) + lane) + Q.s.cx;
+    if constexpr (is_stereo(QK)) xs[q] = stereo_nx(Q, x0 + 64u * uint32_t(q) + lane);
   }
 #pragma unroll 1
   for (uint32_t r = wave; r < uint32_t(S::TH); r += uint32_t(S::THREADS / 64)) {  // a wave takes every fourth row
@@ -514,12 +558,12 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
 #pragma unroll
     for (int q = 0; q < 4; ++q) raw[q] = ob[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
     double ys = 0.0;
-    if constexpr (QK == QK_STEREO) ys = double(y) + Q.s.cy;
+    if constexpr (is_stereo(QK)) ys = stereo_ny(Q, y);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t x = x0 + 64u * uint32_t(q) + lane;
       float X, Y, Z;
-      if constexpr (QK == QK_STEREO) {
+      if constexpr (is_stereo(QK)) {
         const double iw = lut_iw[raw[q]];
         X = float(xs[q] * iw);
         Y = float(ys * iw);
@@ -739,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restr
     const uint32_t base = lt * uint32_t(kBlock * PXT);
     const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
     uint32_t c = 0;
-    if constexpr (QK == QK_STEREO && VEC) {
+    if constexpr (is_stereo(QK) && VEC) {
       // 16 B per lane straight from the rows; the exact predicate needs only d
       // (~4 fp64 operations per pixel), so the pass stays read-bound
       v4f q[PXT / 4];
@@ -766,7 +810,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t *__restr
       }
     } else {
       float *wave_strip = nullptr;  // VEC staging is only worth it for the ordered passes
-      if constexpr (QK == QK_STEREO) {
+      if constexpr (is_stereo(QK)) {
         TileIn<PXT> in;
         tile_load<DT, PXT, false>(in, fin, g, base, wave, lane, wave_strip);
 #pragma unroll
@@ -1056,7 +1100,8 @@ __device__ __forceinline__ void pixel_coords(const Geom &g, uint32_t i, uint32_t
 //   W zero, infinite or NaN (d = +-inf gives +-inf or NaN; no poisoning of d needed)    -> invalid
 //   0 < |W| < w_safe, the "sliver"      => only the real arithmetic can tell (never seen with a real
 //                                          calibration; a tile that holds one takes the exact path)
-__device__ __forceinline__ double stereo_nw(const QArg<QK_STEREO> &A, float d) { return fma(A.s.a, double(d), A.s.b); }
+template <int QK>
+__device__ __forceinline__ double stereo_nw(const QArg<QK> &A, float d) { return stereo_w(A, double(d)); }
 __device__ __forceinline__ bool finite_nonzero(double x) {
   return __builtin_isfpclass(x, 0x0008 | 0x0010 | 0x0080 | 0x0100);  // -normal, -subnormal, +subnormal, +normal
 }
@@ -1079,8 +1124,8 @@ __device__ __forceinline__ bool tile_count(const QArg<QK> &Q, const Geom &g, con
                                            uint32_t wave, uint32_t lane, uint32_t (&cnt)[PXT]) {
   const uint32_t i0 = base + wave * 256u + lane;
   const uint32_t lim = base + uint32_t(kBlock * PXT) > g.roi_n ? g.roi_n : 0xffffffffu;  // ragged: a frame's last tile
-  bool exact = QK != QK_STEREO;
-  if constexpr (QK == QK_STEREO) {
+  bool exact = !is_stereo(QK);
+  if constexpr (is_stereo(QK)) {
     uint64_t sliver = 0;
 #pragma unroll
     for (int k = 0; k < PXT; ++k) {
@@ -1131,7 +1176,7 @@ __device__ __forceinline__ void tile_scatter_lean(const QArg<QK> &Q, const Geom 
     bool ok;
     double nw = 0.0;
     float X, Y, Z;
-    if constexpr (QK == QK_STEREO && !EXACT) {
+    if constexpr (is_stereo(QK) && !EXACT) {
       nw = stereo_nw(Q, d[k]);
       ok = int(finite_nonzero(nw)) & int(fabs(nw) >= Q.s.w_safe) & int(!(d[k] <= g.min_disparity)) & int(i < lim);
     } else {
@@ -1140,10 +1185,10 @@ __device__ __forceinline__ void tile_scatter_lean(const QArg<QK> &Q, const Geom 
     }
     const uint64_t m = __ballot(ok);
     if (m != 0) {  // whole slots of holes (blocky invalid regions) skip the arithmetic and the stores
-      if constexpr (QK == QK_STEREO && !EXACT) {
+      if constexpr (is_stereo(QK) && !EXACT) {
         const double iw = 1.0 / nw;
-        X = float((double(uu) + Q.s.cx) * iw);
-        Y = float((double(vv) + Q.s.cy) * iw);
+        X = float(stereo_nx(Q, uu) * iw);
+        Y = float(stereo_ny(Q, vv) * iw);
         Z = big_z_rule(d[k], float(Q.s.f * iw));
       }
       // rank among the slot's survivors, accumulated onto the cell's base in the same two instructions
@@ -1463,13 +1508,13 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
   uint32_t tk = 0;
   if (tid == 0) {
     tk = atomicAdd(cs.ticket, 1u);  // its round trip (2-3 us under load) runs under the table's divisions
-    s_exact = QK != QK_STEREO ? 1u : 0u;
+    s_exact = !is_stereo(QK) ? 1u : 0u;
   }
   if (tid < 3) s_stat[tid] = 0;
-  if constexpr (QK == QK_STEREO) {
+  if constexpr (is_stereo(QK)) {
     const float d = __fmul_rn(float(tid), g.scale);  // cpp:61, as load_disparity<DT_U8>
     const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
-    const double nw = fma(Q.s.a, double(dsel), Q.s.b);
+    const double nw = stereo_w(Q, double(dsel));
     const double iw = 1.0 / nw;
     lut_iw[tid] = iw;
     lut_z[tid] = big_z_rule(d, float(Q.s.f * iw));
@@ -1494,11 +1539,11 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     xs[q] = 0.0;
-    if constexpr (QK == QK_STEREO) xs[q] = double(x0 + 64u * uint32_t(q) + lane) + Q.s.cx;
+    if constexpr (is_stereo(QK)) xs[q] = stereo_nx(Q, x0 + 64u * uint32_t(q) + lane);
   }
   // one pixel: its point (when wanted) and whether it survives
   auto pixel = [&](uint32_t x, uint32_t y, uint32_t raw, int q, double ys, bool want_point, float &X, float &Y, float &Z) -> bool {
-    if constexpr (QK == QK_STEREO) {
+    if constexpr (is_stereo(QK)) {
       if (!exact && !want_point) return lut_cls[raw] == 1u;
       const double iw = lut_iw[raw];
       X = float(xs[q] * iw);
@@ -1520,7 +1565,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
     uint32_t cnt = 0;
     if (y < y_end) {
       double ys = 0.0;
-      if constexpr (QK == QK_STEREO) ys = double(y) + Q.s.cy;
+      if constexpr (is_stereo(QK)) ys = stereo_ny(Q, y);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t x = x0 + 64u * uint32_t(q) + lane;
@@ -1636,7 +1681,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
     if (y >= y_end) break;
     uint32_t row_pos = s_base[r];
     double ys = 0.0;
-    if constexpr (QK == QK_STEREO) ys = double(y) + Q.s.cy;
+    if constexpr (is_stereo(QK)) ys = stereo_ny(Q, y);
     uint32_t raw[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) raw[q] = ob[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
@@ -1699,17 +1744,17 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
 
   if (tid == 0) {
     s_next = atomicAdd(cs.ticket, 1u);
-    s_exact = QK != QK_STEREO ? 1u : 0u;
+    s_exact = !is_stereo(QK) ? 1u : 0u;
   }
   if (tid < 3) s_stat[tid] = 0;
   __syncthreads();
   uint32_t cur = s_next, prev = kNoTile;
   if (cur >= tpf) cur = kNoTile;
-  bool exact = QK != QK_STEREO;
+  bool exact = !is_stereo(QK);
 
   // one pixel: its point (when wanted) and whether it survives
   auto pixel = [&](uint32_t x, uint32_t y, uint32_t raw, double xs, double ys, bool want_point, float &X, float &Y, float &Z) -> bool {
-    if constexpr (QK == QK_STEREO) {
+    if constexpr (is_stereo(QK)) {
       if (!exact && !want_point) return lut_cls[raw] == 1u;
       const double iw = lut_iw[raw];
       X = float(xs * iw);
@@ -1735,10 +1780,10 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
       // burst, was built and is slower -- 722 -> 788 us: the 12 registers it keeps across the phases spill.)
       median_bs_tile<KS>(fsrc, ma, int(x0), int(y0), s_w, s_raw, tid);
       if (tid == 0) s_next = tk;
-      if constexpr (QK == QK_STEREO) {  // per byte value: 1/W, Z and the validity class (see K1c)
+      if constexpr (is_stereo(QK)) {  // per byte value: 1/W, Z and the validity class (see K1c)
         const float d = __fmul_rn(float(tid), g.scale);
         const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
-        const double nw = fma(Q.s.a, double(dsel), Q.s.b);
+        const double nw = stereo_w(Q, double(dsel));
         const double iw = 1.0 / nw;
         lut_iw[tid] = iw;
         lut_z[tid] = big_z_rule(d, float(Q.s.f * iw));
@@ -1758,13 +1803,13 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         uint32_t cnt = 0;
         if (y < y_end) {
           double ys = 0.0;
-          if constexpr (QK == QK_STEREO) ys = double(y) + Q.s.cy;
+          if constexpr (is_stereo(QK)) ys = stereo_ny(Q, y);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const uint32_t x = x0 + 64u * uint32_t(q) + lane;
             const uint32_t raw = ob[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
             double xs = 0.0;
-            if constexpr (QK == QK_STEREO) xs = double(x) + Q.s.cx;
+            if constexpr (is_stereo(QK)) xs = stereo_nx(Q, x);
             float X, Y, Z;
             const bool ok = pixel(x, y, raw, xs, ys, false, X, Y, Z) && x < x_end;
             cnt += uint32_t(__popcll(__ballot(ok)));
@@ -1865,7 +1910,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         if (y >= y_end) break;
         uint32_t row_pos = s_base[r];
         double ys = 0.0;
-        if constexpr (QK == QK_STEREO) ys = double(y) + Q.s.cy;
+        if constexpr (is_stereo(QK)) ys = stereo_ny(Q, y);
         uint32_t raw[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) raw[q] = kb[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
@@ -1873,7 +1918,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         for (int q = 0; q < 4; ++q) {
           const uint32_t x = x0 + 64u * uint32_t(q) + lane;
           double xs = 0.0;
-          if constexpr (QK == QK_STEREO) xs = double(x) + Q.s.cx;
+          if constexpr (is_stereo(QK)) xs = stereo_nx(Q, x);
           float X, Y, Z;
           const bool ok = pixel(x, y, raw[q], xs, ys, true, X, Y, Z) && x < x_end;
           const uint64_t m = __ballot(ok);
@@ -1927,6 +1972,19 @@ template <>
 QArg<QK_STEREO> make_qarg<QK_STEREO>(const LaunchArgs &a) {
   QArg<QK_STEREO> r;
   r.s = a.qs;
+  return r;
+}
+template <>
+QArg<QK_STEREO_CV24> make_qarg<QK_STEREO_CV24>(const LaunchArgs &a) {
+  QArg<QK_STEREO_CV24> r;
+  r.s = a.qs;
+  r.seg = a.q.seg;  // the running column sum as the host replayed it (fill_q in d2pc_capi.hip)
+  return r;
+}
+template <>
+QArg<QK_STEREO_CV4> make_qarg<QK_STEREO_CV4>(const LaunchArgs &a) {
+  QArg<QK_STEREO_CV4> r;
+  r.s = a.qs;  // (f already rounded to float by the host)
   return r;
 }
 
@@ -2042,8 +2100,13 @@ static hipError_t dispatch_dtype(const LaunchArgs &a, bool compact) {
 
 template <int PXT>
 static hipError_t dispatch_q(const LaunchArgs &a, bool compact) {
-  return a.q_kind == QK_STEREO ? dispatch_dtype<QK_STEREO, PXT>(a, compact)
-                               : dispatch_dtype<QK_GENERAL, PXT>(a, compact);
+  switch (a.q_kind) {
+    case QK_STEREO: return dispatch_dtype<QK_STEREO, PXT>(a, compact);
+    case QK_STEREO_CV24: return dispatch_dtype<QK_STEREO_CV24, PXT>(a, compact);
+    case QK_STEREO_CV4: return dispatch_dtype<QK_STEREO_CV4, PXT>(a, compact);
+    case QK_GENERAL: return dispatch_dtype<QK_GENERAL, PXT>(a, compact);
+  }
+  return hipErrorInvalidValue;
 }
 
 bool tile_shape_supported(int pxt) { return pxt == 4 || pxt == 8 || pxt == 16; }
@@ -2060,12 +2123,20 @@ size_t compact_state_bytes(const Geom &g) {
 
 static hipError_t dispatch(const LaunchArgs &a, bool compact) {
   if (!compact && a.parity_small) {  // the small one-shot tiles (PARITY only)
-    const bool st = a.q_kind == QK_STEREO;
+#define D2PC_SMALL(S)                                                          \
+  switch (a.q_kind) {                                                          \
+    case QK_STEREO: return dispatch_small<QK_STEREO, S>(a);                    \
+    case QK_STEREO_CV24: return dispatch_small<QK_STEREO_CV24, S>(a);          \
+    case QK_STEREO_CV4: return dispatch_small<QK_STEREO_CV4, S>(a);            \
+    case QK_GENERAL: return dispatch_small<QK_GENERAL, S>(a);                  \
+  }                                                                            \
+  return hipErrorInvalidValue
     switch (a.pxt) {
-      case 1: return st ? dispatch_small<QK_STEREO, 1>(a) : dispatch_small<QK_GENERAL, 1>(a);
-      case 2: return st ? dispatch_small<QK_STEREO, 2>(a) : dispatch_small<QK_GENERAL, 2>(a);
-      case 4: return st ? dispatch_small<QK_STEREO, 4>(a) : dispatch_small<QK_GENERAL, 4>(a);
+      case 1: D2PC_SMALL(1);
+      case 2: D2PC_SMALL(2);
+      case 4: D2PC_SMALL(4);
     }
+#undef D2PC_SMALL
     return hipErrorInvalidValue;
   }
   switch (a.pxt) {
@@ -2091,17 +2162,28 @@ hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src
 #define D2PC_CB_BS(KS, QK)                                                                                              \
   hipLaunchKernelGGL((k_callback_bs<KS, QK>), dim3(uint32_t(blocks)), dim3(S::THREADS), 0, a.stream, s8, o, a.out_index, \
                      a.counts, m, a.geom, make_qarg<QK>(a))
-  switch (ksize * 2 + (a.q_kind == QK_STEREO ? 1 : 0)) {
-    case 6: D2PC_CB_BS(3, QK_GENERAL); break;
-    case 7: D2PC_CB_BS(3, QK_STEREO); break;
-    case 10: D2PC_CB_BS(5, QK_GENERAL); break;
-    case 11: D2PC_CB_BS(5, QK_STEREO); break;
-    case 14: D2PC_CB_BS(7, QK_GENERAL); break;
-    case 15: D2PC_CB_BS(7, QK_STEREO); break;
-    case 18: D2PC_CB_BS(9, QK_GENERAL); break;
-    case 19: D2PC_CB_BS(9, QK_STEREO); break;
-    case 22: D2PC_CB_BS(11, QK_GENERAL); break;
-    case 23: D2PC_CB_BS(11, QK_STEREO); break;
+  if (a.q_kind < QK_GENERAL || a.q_kind > QK_STEREO_CV4) return hipErrorInvalidValue;
+  switch (ksize * 4 + a.q_kind) {
+    case 12: D2PC_CB_BS(3, QK_GENERAL); break;
+    case 13: D2PC_CB_BS(3, QK_STEREO); break;
+    case 14: D2PC_CB_BS(3, QK_STEREO_CV24); break;
+    case 15: D2PC_CB_BS(3, QK_STEREO_CV4); break;
+    case 20: D2PC_CB_BS(5, QK_GENERAL); break;
+    case 21: D2PC_CB_BS(5, QK_STEREO); break;
+    case 22: D2PC_CB_BS(5, QK_STEREO_CV24); break;
+    case 23: D2PC_CB_BS(5, QK_STEREO_CV4); break;
+    case 28: D2PC_CB_BS(7, QK_GENERAL); break;
+    case 29: D2PC_CB_BS(7, QK_STEREO); break;
+    case 30: D2PC_CB_BS(7, QK_STEREO_CV24); break;
+    case 31: D2PC_CB_BS(7, QK_STEREO_CV4); break;
+    case 36: D2PC_CB_BS(9, QK_GENERAL); break;
+    case 37: D2PC_CB_BS(9, QK_STEREO); break;
+    case 38: D2PC_CB_BS(9, QK_STEREO_CV24); break;
+    case 39: D2PC_CB_BS(9, QK_STEREO_CV4); break;
+    case 44: D2PC_CB_BS(11, QK_GENERAL); break;
+    case 45: D2PC_CB_BS(11, QK_STEREO); break;
+    case 46: D2PC_CB_BS(11, QK_STEREO_CV24); break;
+    case 47: D2PC_CB_BS(11, QK_STEREO_CV4); break;
     default: return hipErrorInvalidValue;
   }
 #undef D2PC_CB_BS
@@ -2148,17 +2230,28 @@ hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const v
   else                                                                                                                       \
     hipLaunchKernelGGL((k_callback_bs_compact<KS, QK>), dim3(grid), dim3(S::THREADS), 0, a.stream, s8, o, a.out_index,      \
                        a.counts, state, m, a.geom, make_qarg<QK>(a))
-  switch (ksize * 2 + (a.q_kind == QK_STEREO ? 1 : 0)) {
-    case 6: D2PC_CB_BSC(3, QK_GENERAL); break;
-    case 7: D2PC_CB_BSC(3, QK_STEREO); break;
-    case 10: D2PC_CB_BSC(5, QK_GENERAL); break;
-    case 11: D2PC_CB_BSC(5, QK_STEREO); break;
-    case 14: D2PC_CB_BSC(7, QK_GENERAL); break;
-    case 15: D2PC_CB_BSC(7, QK_STEREO); break;
-    case 18: D2PC_CB_BSC(9, QK_GENERAL); break;
-    case 19: D2PC_CB_BSC(9, QK_STEREO); break;
-    case 22: D2PC_CB_BSC(11, QK_GENERAL); break;
-    case 23: D2PC_CB_BSC(11, QK_STEREO); break;
+  if (a.q_kind < QK_GENERAL || a.q_kind > QK_STEREO_CV4) return hipErrorInvalidValue;
+  switch (ksize * 4 + a.q_kind) {
+    case 12: D2PC_CB_BSC(3, QK_GENERAL); break;
+    case 13: D2PC_CB_BSC(3, QK_STEREO); break;
+    case 14: D2PC_CB_BSC(3, QK_STEREO_CV24); break;
+    case 15: D2PC_CB_BSC(3, QK_STEREO_CV4); break;
+    case 20: D2PC_CB_BSC(5, QK_GENERAL); break;
+    case 21: D2PC_CB_BSC(5, QK_STEREO); break;
+    case 22: D2PC_CB_BSC(5, QK_STEREO_CV24); break;
+    case 23: D2PC_CB_BSC(5, QK_STEREO_CV4); break;
+    case 28: D2PC_CB_BSC(7, QK_GENERAL); break;
+    case 29: D2PC_CB_BSC(7, QK_STEREO); break;
+    case 30: D2PC_CB_BSC(7, QK_STEREO_CV24); break;
+    case 31: D2PC_CB_BSC(7, QK_STEREO_CV4); break;
+    case 36: D2PC_CB_BSC(9, QK_GENERAL); break;
+    case 37: D2PC_CB_BSC(9, QK_STEREO); break;
+    case 38: D2PC_CB_BSC(9, QK_STEREO_CV24); break;
+    case 39: D2PC_CB_BSC(9, QK_STEREO_CV4); break;
+    case 44: D2PC_CB_BSC(11, QK_GENERAL); break;
+    case 45: D2PC_CB_BSC(11, QK_STEREO); break;
+    case 46: D2PC_CB_BSC(11, QK_STEREO_CV24); break;
+    case 47: D2PC_CB_BSC(11, QK_STEREO_CV4); break;
     default: return hipErrorInvalidValue;
   }
 #undef D2PC_CB_BSC

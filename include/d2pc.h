@@ -180,8 +180,10 @@ int d2pc_set_mode(d2pc_ctx *ctx, int mode);
  *                      makes the next call return D2PC_ERR_INVALID_ARG
  *   D2PC_FORM_CV4      OpenCV 3/4's form bit for bit for every Q (Matx product
  *                      left to right, numerators cast to float, times 1./W)
- * The two exact forms run in double without contraction and cost arithmetic:
- * profiles/r03_ab_forms.txt has them beside the default. */
+ * For cv::stereoRectify's Q the exact forms have kernels of their own and cost
+ * about as much as the default; any other Q runs them in the general kernel
+ * (double, no contraction), which is arithmetic-bound:
+ * profiles/r03_ab_forms.txt has all of them beside the default. */
 typedef enum d2pc_reproject_form {
   D2PC_FORM_DEFAULT = 0,
   D2PC_FORM_CV24 = 24,

@@ -347,9 +347,10 @@ def test_tile_fused_callback_kernel_matches_the_two_launches_and_the_oracle(gene
         assert_points_close(pts[f][:len(want)], want, max_ulp=ulp, rel=1e-5, what=f"frame {f}")
 
 
+@pytest.mark.parametrize("general", [0, 1])
 @pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
 @pytest.mark.parametrize("form,oform", [(24, oracle.FORM_CV24), (4, oracle.FORM_CV4)])
-def test_callback_body_in_one_opencv_generation_bit_for_bit(mode, form, oform):
+def test_callback_body_in_one_opencv_generation_bit_for_bit(mode, form, oform, general):
     """cpp:55-85 as a node linked against OpenCV 2.4 (form 24) or 3/4 (form 4) computes it: median, x 1/8, that
     generation's reprojectImageTo3D arithmetic, ROI pack -- 0 ulp, one kernel and two launches."""
     from disparity_to_point_cloud_amd.torch_api import DeviceBatch
@@ -361,9 +362,10 @@ def test_callback_body_in_one_opencv_generation_bit_for_bit(mode, form, oform):
     key = "callback_fused" if mode == d2pc.MODE_PARITY else "callback_fused_compact"
     with d2pc.Context(q=q, border=40, mode=mode) as ctx:
         ctx.set_tuning("reproject_form", form)
+        ctx.set_tuning("force_general_q", general)   # 0: the specialised kinds (tables of 1/W per byte value), 1: the general kernel
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
-        for fused in (1, 0):
+        for fused in ((2, 1, 0) if mode == d2pc.MODE_COMPACT else (1, 0)):
             ctx.set_tuning(key, fused)
             b.points.fill_(0); b.index.fill_(-1); b.counts.fill_(0)
             ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125, b.points.data_ptr(),

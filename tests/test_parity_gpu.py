@@ -332,16 +332,24 @@ def test_reproject_form_selects_one_opencv_generation_bit_for_bit(w, h, border, 
     disp = synth_disparity(3, w + h, w, h, "holes")
     disp[h // 2, w // 2 : w // 2 + 6] = [np.nan, np.inf, -np.inf, -1.0, 3.4028235e38, 1e-45][: min(6, w - w // 2)]
     for form, oform in ((24, oracle.FORM_CV24), (4, oracle.FORM_CV4)):
-        with ctx_for(q, border=border) as ctx:
-            ctx.set_reproject_form(form)
-            _same_bits(ctx.process(disp), oracle.reproject(disp, q, border=border, form=oform), f"form {form} {w}x{h}")
+        want = oracle.reproject(disp, q, border=border, form=oform)
         wp, wi = oracle.reproject_compact(disp, q, border=border, form=oform)
-        for algo in (1, 2, 3):
-            with ctx_for(q, border=border, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
-                ctx.set_tuning("reproject_form", form)
-                gp, gi = ctx.process(disp, want_index=True)
-            assert np.array_equal(gi, wi)
-            _same_bits(gp, wp, f"compact (algo {algo}) form {form} {w}x{h}")
+        # two independent routes to the same bytes: the specialised kinds (QK_STEREO_CV24 / _CV4: the generation's
+        # roundings on stereoRectify's structure) and the general kernel in that generation's form
+        for general in (0, 1):
+            with ctx_for(q, border=border) as ctx:
+                ctx.set_reproject_form(form)
+                ctx.set_tuning("force_general_q", general)
+                _same_bits(ctx.process(disp), want, f"form {form} general={general} {w}x{h}")
+                ctx.set_tuning("pxt_parity", 8)   # the tile-walking kernel too
+                _same_bits(ctx.process(disp), want, f"form {form} general={general} {w}x{h} (tiles)")
+            for algo in (1, 2, 3):
+                with ctx_for(q, border=border, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+                    ctx.set_reproject_form(form)
+                    ctx.set_tuning("force_general_q", general)
+                    gp, gi = ctx.process(disp, want_index=True)
+                assert np.array_equal(gi, wi)
+                _same_bits(gp, wp, f"compact (algo {algo}) form {form} general={general} {w}x{h}")
 
 
 def test_reproject_form_24_u8_and_scale(q_default):

@@ -48,8 +48,10 @@ for c in range(cases):
     frames[rng.random((n, h, w)) < holes] = 0
     m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
     rform = int(rng.choice([0, 0, 24, 4])) if stereo else int(rng.choice([0, 4]))   # d2pc_set_reproject_form
+    fgen = bool(stereo and rng.random() < 0.3)   # stereoRectify's Q through the general kernel (the other route to the same bytes)
     with d2pc.Context(q=q, border=border, mode=m, compact_algo=algo) as ctx:
         ctx.set_reproject_form(rform)
+        ctx.set_tuning("force_general_q", int(fgen))
         b = DeviceBatch(ctx, n, h, w, dtype=tdt, want_index=idx)
         b.disp.copy_(torch.from_numpy(frames.view(np.int16) if dt == "u16" else frames).view(tdt))
         b.launch(scale=scale)
@@ -60,10 +62,10 @@ for c in range(cases):
     # multiply-adds were up to 71 float ulp from the 2.4 form where a numerator cancels: that loosened bar is gone).
     # stereoRectify-structured Q: the specialised kernel, 1 ulp from the 2.4 form.
     # An explicit form (24: OpenCV 2.4's loop, 4: OpenCV 3/4's) is that generation bit for bit, for stereoRectify's Q too.
-    ulp, form = (1, oracle.FORM_CV24) if stereo else (0, oracle.FORM_CV4)
+    ulp, form = (1, oracle.FORM_CV24) if stereo and not fgen else (0, oracle.FORM_CV4)
     if rform:
         ulp, form = 0, (oracle.FORM_CV24 if rform == 24 else oracle.FORM_CV4)
-    what = f"case {c}: n={n} {w}x{h} b={border} {dt} {mode} algo={algo} idx={idx} holes={holes} stereo={stereo} form={rform}"
+    what = f"case {c}: n={n} {w}x{h} b={border} {dt} {mode} algo={algo} idx={idx} holes={holes} stereo={stereo} form={rform} general_route={fgen}"
     for f in range(n):
         if m == d2pc.MODE_PARITY:
             want = oracle.reproject(frames[f], q, border=border, scale=scale, form=form)
