@@ -209,11 +209,28 @@ def device_calibration(ctx, batch):
 
     f = spread(timed_rounds(_Fill(), 5))
     c = spread(timed_rounds(_Copy(), 5))
-    return {"device_fill_GBs": round(nbytes / (f["median"] * 1e-3) / 1e9, 1),
-            "device_copy_GBs": round(2 * half / (c["median"] * 1e-3) / 1e9, 1),
-            "device_fill_ms": f, "device_copy_ms": c, "calibration_bytes": nbytes,
-            "calibration_what": "k_membench_fill over the bench's output buffer; k_membench_copy of its first half onto "
-                                "its second (bytes read + written); medians of >= 100 ms of rounds of 5 launches"}
+    out = {"device_fill_GBs": round(nbytes / (f["median"] * 1e-3) / 1e9, 1),
+           "device_copy_GBs": round(2 * half / (c["median"] * 1e-3) / 1e9, 1),
+           "device_fill_ms": f, "device_copy_ms": c, "calibration_bytes": nbytes,
+           "calibration_what": "k_membench_fill over the bench's output buffer; k_membench_copy of its first half onto "
+                               "its second (bytes read + written); medians of >= 100 ms of rounds of 5 launches. "
+                               "device_fill / device_copy: persistent blocks, plain stores (the single pass's shape; "
+                               "device classes differ by ~15 % on it); *_oneshot_*: one block per 4 KiB, one 16-byte "
+                               "access per thread (the headline kernel's shape: the ceiling of a store stream here)"}
+    # the headline kernel's launch shape: one-shot blocks, plain and non-temporal
+    ctx.set_tuning("membench_blocks_per_cu", 0)
+    ctx.set_tuning("membench_unroll", 1)
+    for nt in (0, 1):
+        ctx.set_tuning("membench_nt", nt)
+        f1 = spread(timed_rounds(_Fill(), 5))
+        c1 = spread(timed_rounds(_Copy(), 5))
+        tag = "nt" if nt else "plain"
+        out[f"device_fill_oneshot_{tag}_GBs"] = round(nbytes / (f1["median"] * 1e-3) / 1e9, 1)
+        out[f"device_copy_oneshot_{tag}_GBs"] = round(2 * half / (c1["median"] * 1e-3) / 1e9, 1)
+    ctx.set_tuning("membench_blocks_per_cu", 8)
+    ctx.set_tuning("membench_unroll", 4)
+    ctx.set_tuning("membench_nt", 0)
+    return out
 
 
 def compaction_counters(ctx):
@@ -475,6 +492,12 @@ def main():
         out["roofline"].update(cal)
         out["roofline"]["achieved_over_device_fill"] = round(achieved / cal["device_fill_GBs"], 4)
         out["roofline"]["achieved_over_device_copy"] = round(achieved / cal["device_copy_GBs"], 4)
+        # against the best streams of the kernel's own launch shape on this device: a 1:4 read:write stream sits
+        # between a copy (1:1) and a fill (0:1)
+        best_fill = max(cal["device_fill_oneshot_plain_GBs"], cal["device_fill_oneshot_nt_GBs"])
+        best_copy = max(cal["device_copy_oneshot_plain_GBs"], cal["device_copy_oneshot_nt_GBs"])
+        out["roofline"]["achieved_over_device_oneshot_fill"] = round(achieved / best_fill, 4)
+        out["roofline"]["achieved_over_device_oneshot_copy"] = round(achieved / best_copy, 4)
         if mode == d2pc.MODE_COMPACT:
             out["roofline"]["compaction_counters"] = compaction_counters(ctx)
     if a.share_gpu:

@@ -110,7 +110,9 @@ struct d2pc_ctx {
   uint32_t *d_counts = nullptr;
   uint32_t *h_counts = nullptr;  // pinned
   CompactStats *d_stats = nullptr;  // single-pass counters, added to by the launches' blocks (d2pc_compact_stats)
-  int membench_blocks_per_cu = 8;
+  int membench_blocks_per_cu = 8;  // 0: one-shot blocks (one per membench_unroll x 4 KiB)
+  int membench_unroll = 4;         // 16-byte accesses per thread and step: 1, 2 or 4
+  int membench_nt = 0;             // non-temporal stores
   // d2pc_process_mono_device: two internal streams + scratch for the filtered frames
   int cb_fused_compact = 2;      // ... and the COMPACT form of that kernel: 2 = persistent blocks, software-pipelined over their
                                  // tiles (k_callback_bs_compact_pipe; the default: 16 x 4K with 30 % holes + indices 711 us
@@ -950,7 +952,9 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "host_direct_read") && (value == 0 || value == 1)) ctx->host_direct_read = value;
   else if (!strcmp(key, "median_algo") && value >= 0 && value <= 2) ctx->median_algo = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
-  else if (!strcmp(key, "membench_blocks_per_cu") && value >= 1 && value <= 256) ctx->membench_blocks_per_cu = value;
+  else if (!strcmp(key, "membench_blocks_per_cu") && value >= 0 && value <= 256) ctx->membench_blocks_per_cu = value;
+  else if (!strcmp(key, "membench_unroll") && (value == 1 || value == 2 || value == 4)) ctx->membench_unroll = value;
+  else if (!strcmp(key, "membench_nt") && (value == 0 || value == 1)) ctx->membench_nt = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
   return D2PC_OK;
 }
@@ -1101,8 +1105,8 @@ int d2pc_membench_fill(d2pc_ctx *ctx, void *d_dst, size_t bytes, void *stream) {
     return fail(ctx, D2PC_ERR_INVALID_ARG, "fill needs a 16-byte aligned buffer of a multiple of 16 bytes");
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
-  D2PC_HIP(ctx, launch_membench_fill(d_dst, bytes, uint32_t(ctx->cu_count * ctx->membench_blocks_per_cu),
-                                     static_cast<hipStream_t>(stream)));
+  D2PC_HIP(ctx, launch_membench_fill(d_dst, bytes, uint32_t(ctx->cu_count * ctx->membench_blocks_per_cu), ctx->membench_unroll,
+                                     ctx->membench_nt != 0, static_cast<hipStream_t>(stream)));
   return D2PC_OK;
 }
 
@@ -1115,8 +1119,8 @@ int d2pc_membench_copy(d2pc_ctx *ctx, const void *d_src, void *d_dst, size_t byt
   if (s0 < d0 + bytes && d0 < s0 + bytes) return fail(ctx, D2PC_ERR_INVALID_ARG, "source and destination overlap");
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
-  D2PC_HIP(ctx, launch_membench_copy(d_src, d_dst, bytes, uint32_t(ctx->cu_count * ctx->membench_blocks_per_cu),
-                                     static_cast<hipStream_t>(stream)));
+  D2PC_HIP(ctx, launch_membench_copy(d_src, d_dst, bytes, uint32_t(ctx->cu_count * ctx->membench_blocks_per_cu), ctx->membench_unroll,
+                                     ctx->membench_nt != 0, static_cast<hipStream_t>(stream)));
   return D2PC_OK;
 }
 

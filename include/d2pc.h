@@ -441,6 +441,9 @@ int d2pc_compact_stats_reset(d2pc_ctx *ctx);
  * wave instruction), asynchronous on `stream`.  bench.py times them in the same run as the reprojection kernel,
  * so its fraction of the 8 TB/s specification can also be read against what THIS device gives a kernel that only
  * streams.  Buffers 16-byte aligned, `bytes` a multiple of 16, source and destination disjoint.
+ * Launch shape by tuning keys (d2pc_set_tuning): persistent grid-stride blocks (default; the single-pass kernels'
+ * shape) or one-shot blocks (the headline kernel's shape, the fastest store stream found on the chip), plain or
+ * non-temporal stores.
  */
 int d2pc_membench_fill(d2pc_ctx *ctx, void *d_dst, size_t bytes, void *stream);
 int d2pc_membench_copy(d2pc_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, void *stream);
@@ -533,7 +536,8 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
  * "callback_fused" (0/1, see d2pc_process_mono_device; default 1), "callback_fused_compact" (COMPACT mode: 0 = two
  * launches, 1 = one tile per block, 2 = persistent blocks that scatter one tile while filtering the next; default 2),
- * "callback_pipe_blocks_per_cu" (1..8, default 3), "membench_blocks_per_cu" (d2pc_membench_*),
+ * "callback_pipe_blocks_per_cu" (1..8, default 3), "membench_blocks_per_cu" (d2pc_membench_*: persistent blocks per CU, default 8; 0 = one block per
+ * "membench_unroll" x 4 KiB), "membench_unroll" (1, 2 or 4 16-byte accesses per thread), "membench_nt" (0/1),
  * "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process / d2pc_process_mono8
  * without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose per launch,
  * 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes). */

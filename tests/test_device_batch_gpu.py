@@ -331,9 +331,14 @@ def test_compact_stats_count_the_single_pass_launches():
         assert ctx.compact_stats()["launches"] == 0
 
 
-def test_membench_kernels_fill_and_copy():
-    """The calibration kernels bench.py times next to the reprojection: every byte written / copied."""
+@pytest.mark.parametrize("blocks_per_cu,unroll,nt", [(8, 4, 0), (0, 1, 0), (0, 1, 1), (0, 2, 1), (0, 4, 0), (3, 2, 1)])
+def test_membench_kernels_fill_and_copy(blocks_per_cu, unroll, nt):
+    """The calibration kernels bench.py times next to the reprojection, in every launch shape it uses (persistent
+    blocks / one-shot blocks, plain / non-temporal stores): every byte written / copied, none beyond."""
     with d2pc.Context(q=d2pc.make_q()) as ctx:
+        ctx.set_tuning("membench_blocks_per_cu", blocks_per_cu)
+        ctx.set_tuning("membench_unroll", unroll)
+        ctx.set_tuning("membench_nt", nt)
         n = (1 << 20) + 48
         buf = torch.zeros(2 * n, dtype=torch.uint8, device="cuda")
         s = torch.cuda.current_stream().cuda_stream
@@ -345,9 +350,11 @@ def test_membench_kernels_fill_and_copy():
         src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
         ctx.membench_copy(src.data_ptr(), buf.data_ptr() + n, n, s)
         torch.cuda.synchronize()
-        assert torch.equal(buf[n:], src)
+        assert torch.equal(buf[n:], src) and np.array_equal(buf[:n].cpu().numpy(), want)
         with pytest.raises(d2pc.D2pcError):
             ctx.membench_copy(buf.data_ptr(), buf.data_ptr() + 16, n, s)   # overlap
+        with pytest.raises(d2pc.D2pcError):
+            ctx.set_tuning("membench_unroll", 3)
 
 
 def test_resident_one_launch_compaction_over_many_relaunches_and_sizes():
