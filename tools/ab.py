@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--modes", default="parity")
     ap.add_argument("--borders", default="40")
     ap.add_argument("--pxts", default="16")
-    ap.add_argument("--bpcs", default="16")
+    ap.add_argument("--bpcs", default="128", help="tuning blocks_per_cu (library default 128: two-pass and tile-walking grids = min(T, max(CUs x this, T/4)))")
     ap.add_argument("--novecs", default="0")
     ap.add_argument("--algos", default="1")
     ap.add_argument("--idx", type=int, default=0)
