@@ -14,13 +14,14 @@ builds = sorted({r["config"].get("build", "?") for r in runs})
 print(f"# python bench.py (defaults: --steps {runs[0]['steps']} --warmup {runs[0]['warmup']}), {len(runs)} gpurun calls = {len(runs)} device draws, "
       f"build {', '.join(builds)} (inputs: {', '.join(p.split('/')[-1] for p in sys.argv[1:])}).")
 print("# per variant: median ms per launch over rounds that sum to >= 100 ms (fraction of 8 TB/s); 'two:' = the same work as two launches")
-print("headline: contract ms/step | frac | sustained median ms (frac) | device fill GB/s | device copy GB/s")
+print("headline: contract ms/step | frac | sustained median ms (frac) | device fill / copy GB/s, persistent blocks | one-shot blocks (plain, nt)")
 cells = []
 for r in runs:
     ro = r["roofline"]
     sp = ro.get("kernel_ms_spread", {})
     fr = ro.get("frac_at_min_median_max_ms", [None, None, None])
-    cells.append(f"{r['ms_per_step']} | {ro['frac']} | {sp.get('median')} ({fr[1]}) | {ro.get('device_fill_GBs')} | {ro.get('device_copy_GBs')}")
+    cells.append(f"{r['ms_per_step']} | {ro['frac']} | {sp.get('median')} ({fr[1]}) | {ro.get('device_fill_GBs')} / {ro.get('device_copy_GBs')} | "
+                 f"{ro.get('device_fill_oneshot_plain_GBs')}, {ro.get('device_fill_oneshot_nt_GBs')} / {ro.get('device_copy_oneshot_plain_GBs')}, {ro.get('device_copy_oneshot_nt_GBs')}")
 print("    " + "  ||  ".join(cells))
 names = []
 for r in runs:
