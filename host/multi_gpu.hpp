@@ -6,6 +6,7 @@
 //
 //   d2pc_replay --gpus N [--devices a,b,..] [--device D] [--frames F] [--width W --height H] [--encoding mono8|mono16]
 //               [--median K] [--compact] [--depth P] [--in frame.raw] [--out prefix] [name=value ...]
+//               (name=value: the private parameters fx_ fy_ cx_ cy_ base_line_, and reproject_form=0|24|4)
 //
 //   * ncclCommInitAll over the N devices (RCCL; xGMI between the GPUs of a node)
 //   * rank 0 owns the calibration (hpp:84-104: the private parameters -> Q): it packs the 136-byte blob
@@ -48,6 +49,7 @@ struct Options {
   int depth = 3;                // frames in flight per rank
   std::string in_path, out_prefix;
   double fx = 714.24, fy = 713.5, cx = 376, cy = 240, base_line = 0.09;  // hpp:66-71
+  int reproject_form = 0;       // d2pc_set_reproject_form on every rank (0, 24, 4)
   std::string error;            // non-empty: bad command line
 };
 
@@ -120,6 +122,7 @@ inline Options parse(int argc, char **argv) {
       else if (k == "cx_") o.cx = v;
       else if (k == "cy_") o.cy = v;
       else if (k == "base_line_") o.base_line = v;
+      else if (k == "reproject_form") o.reproject_form = int(v);
       else bad("unknown parameter");
     } else if (multi) {
       bad("unknown argument");
@@ -216,6 +219,7 @@ inline void run_rank(const Options &o, int rank, int device, const unsigned char
     ~Guard() { d2pc_destroy(c); }
   } guard{ctx};
   if ((st = d2pc_import_calibration(ctx, blob, D2PC_CALIB_BLOB_BYTES)) != D2PC_OK) return fail("d2pc_import_calibration", ctx, st);
+  if ((st = d2pc_set_reproject_form(ctx, o.reproject_form)) != D2PC_OK) return fail("reproject_form", ctx, st);
   if ((st = d2pc_pipeline_configure(ctx, o.depth, 1)) != D2PC_OK) return fail("d2pc_pipeline_configure", ctx, st);
   const bool m16 = o.encoding == "mono16";
   d2pc_frame_desc desc;
