@@ -51,6 +51,13 @@ int main(int argc, char *argv[]) {
     double v;
     if (nh.getParam(name, v)) params.values[name] = v;
   }
+  // ~reproject_form (not in the reference): which cv::reprojectImageTo3D arithmetic the published bytes reproduce
+  // (d2pc_set_reproject_form).  Default: that of the OpenCV THIS node is built against -- 2.4's loop or 3/4's Matx
+  // form, bit for bit --, so that replacing the reference node changes no published byte; 0 = the form within 1 ulp
+  // of both.
+  int form = CV_MAJOR_VERSION >= 3 ? D2PC_FORM_CV4 : D2PC_FORM_CV24;
+  nh.param("reproject_form", form, form);
+  params.values["reproject_form"] = form;
   double fx = 714.24, fy = 713.5, cx = 376, cy = 240, b = 0.09;
   params.param("fx_", fx, fx); params.param("fy_", fy, fy); params.param("cx_", cx, cx);
   params.param("cy_", cy, cy); params.param("base_line_", b, b);

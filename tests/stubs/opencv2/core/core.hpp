@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #define CV_8U 0
+#define CV_MAJOR_VERSION 4
 #define CV_64F 6
 #define CV_64FC1 6
 namespace cv {
