@@ -51,19 +51,32 @@ __global__ __launch_bounds__(MedianShape<KS>::THREADS) void k_median_u8(const ui
 // saturate_cast<uchar>(cvRound(v * (float)(255./65535.))), product in float,
 // round-half-to-even.  Eight pixels per thread (one 16-byte load, one 8-byte store when aligned).
 // ---------------------------------------------------------------------------
+// Two index forms (tools/mono16_bench.py; the first form of this kernel recovered (x, y, frame) from one flat 64-bit
+// index -- three 64-bit divisions per thread, more instructions than the eight conversions):
+//   ROWS   grid = (groups of 8 pixels / block, rows, frames): no division; the last wave of every row is part empty,
+//          so it serves rows that fill their waves to >= 90 % (4K: 480 groups, 1080p: 240)
+//   flat   grid = (groups x rows / 256, frames): one 32-bit division per thread; every wave full (752 pixels = 94 groups)
+template <bool ROWS>
 __global__ __launch_bounds__(kBlock) void k_mono16_to_mono8(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                             const MedianArgs a) {
-  const uint32_t groups = (a.width + 7u) / 8u;  // eight pixels per thread and row
-  const uint64_t total = uint64_t(groups) * a.height * a.n_frames;
+  const uint32_t groups = (a.width + 7u) / 8u;
+  uint32_t y, gx;
+  if constexpr (ROWS) {
+    gx = blockIdx.x * blockDim.x + threadIdx.x;
+    y = blockIdx.y;
+    if (gx >= groups) return;
+  } else {
+    const uint32_t i = blockIdx.x * uint32_t(kBlock) + threadIdx.x;
+    if (i >= groups * a.height) return;
+    y = i / groups;
+    gx = i - y * groups;
+  }
   const float scale = float(255. / 65535.);
   auto cvt = [&](uint32_t v) {
     const float r = __builtin_rintf(float(v) * scale);  // default rounding mode: nearest-even
     return uint32_t(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
   };
-  for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < total; i += uint64_t(gridDim.x) * kBlock) {
-    const uint32_t gx = uint32_t(i % groups);
-    const uint64_t r = i / groups;
-    const uint32_t y = uint32_t(r % a.height), f = uint32_t(r / a.height);
+  for (uint32_t f = ROWS ? blockIdx.z : blockIdx.y; f < a.n_frames; f += ROWS ? gridDim.z : gridDim.y) {
     const uint8_t *srow = src + uint64_t(f) * a.src_frame_stride + uint64_t(y) * a.src_row_stride;
     uint8_t *drow = dst + uint64_t(f) * a.dst_frame_stride + uint64_t(y) * a.dst_row_stride;
     const uint32_t x = gx * 8u;
@@ -83,12 +96,20 @@ __global__ __launch_bounds__(kBlock) void k_mono16_to_mono8(const uint8_t *__res
 }
 
 hipError_t launch_mono16_to_mono8(const void *src, void *dst, const MedianArgs &a, hipStream_t stream) {
-  const uint64_t total = uint64_t((a.width + 7u) / 8u) * a.height * a.n_frames;
-  if (total == 0) return hipErrorInvalidValue;
-  const uint64_t want = (total + kBlock - 1) / kBlock;
-  const uint32_t grid = uint32_t(want < 65536u ? want : 65536u);
-  hipLaunchKernelGGL(k_mono16_to_mono8, dim3(grid), dim3(kBlock), 0, stream, static_cast<const uint8_t *>(src),
-                     static_cast<uint8_t *>(dst), a);
+  const uint32_t groups = (a.width + 7u) / 8u;
+  if (groups == 0 || a.height == 0 || a.n_frames == 0 || a.height > 65535u) return hipErrorInvalidValue;
+  const uint32_t frames = a.n_frames < 65535u ? a.n_frames : 65535u;
+  const uint8_t *s8 = static_cast<const uint8_t *>(src);
+  uint8_t *d8 = static_cast<uint8_t *>(dst);
+  const uint32_t waves = (groups + 63u) / 64u;
+  if (groups * 10u >= waves * 64u * 9u) {  // rows fill their waves: the division-free grid
+    const uint32_t block = waves * 64u < uint32_t(kBlock) ? waves * 64u : uint32_t(kBlock);
+    hipLaunchKernelGGL(k_mono16_to_mono8<true>, dim3((groups + block - 1) / block, a.height, frames), dim3(block), 0, stream, s8, d8, a);
+  } else {
+    if (uint64_t(groups) * a.height > 0xffffffffull) return hipErrorInvalidValue;
+    const uint32_t per_frame = groups * a.height;
+    hipLaunchKernelGGL(k_mono16_to_mono8<false>, dim3((per_frame + kBlock - 1) / kBlock, frames), dim3(kBlock), 0, stream, s8, d8, a);
+  }
   return hipGetLastError();
 }
 
