@@ -354,13 +354,30 @@ hipError_t launch_fuse(FuseArgs a, hipStream_t stream, int rows_hint) {
 // ---------------------------------------------------------------------------
 // rotateMat (reference src/depth_map_fusion.cpp:268-273): cv::transpose then
 // cv::flip(.., 1) = 90 degrees clockwise; dst has `cols` rows of `rows`
-// pixels, dst(i, j) = src(rows-1-j, i).  64 x 64 byte tiles through LDS: rows
-// are read and written as dwords, the transposition is the LDS gather.
+// pixels, dst(i, j) = src(rows-1-j, i).
+// 128 x 128 byte tiles through LDS (round 3; rounds 1-2 moved 64 x 64 tiles as dwords and gathered single bytes from
+// LDS: every wave instruction touched 64-byte pieces of four rows and the gather cost one LDS read per byte --
+// 3.5 TB/s).  Loads: a wave instruction covers two source rows of 128 bytes; the rows land in LDS as they are.
+// Stores: thread (rg, cd) reads the dword column cd of the 16 source rows 16 rg .. 16 rg + 15, transposes the four
+// 4 x 4 byte blocks in registers (two v_perm levels) and stores 16 consecutive bytes to each of the four destination
+// rows 4 cd .. 4 cd + 3; a wave instruction covers eight destination rows of 128 bytes.
 // ---------------------------------------------------------------------------
-constexpr int kRotTile = 64;
+constexpr int kRotTile = 128;
+constexpr int kRotStride = 33;  // dwords per staged row: the store phase's column reads of 8 row groups x 8 columns
+                                // spread over 32 banks (2-way), the load phase's row writes are conflict-free
+
+__device__ __forceinline__ void rot_transpose_4x4(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t (&o)[4]) {
+  // o[i] = (byte i of b0, of b1, of b2, of b3), lowest address first
+  const uint32_t a0 = __builtin_amdgcn_perm(b1, b0, 0x05010400u), a1 = __builtin_amdgcn_perm(b1, b0, 0x07030602u);
+  const uint32_t a2 = __builtin_amdgcn_perm(b3, b2, 0x05010400u), a3 = __builtin_amdgcn_perm(b3, b2, 0x07030602u);
+  o[0] = __builtin_amdgcn_perm(a2, a0, 0x05040100u);
+  o[1] = __builtin_amdgcn_perm(a2, a0, 0x07060302u);
+  o[2] = __builtin_amdgcn_perm(a3, a1, 0x05040100u);
+  o[3] = __builtin_amdgcn_perm(a3, a1, 0x07060302u);
+}
 
 __global__ __launch_bounds__(kBlock) void k_rotate_cw(const RotateArgs a) {
-  __shared__ uint8_t tile[kRotTile][kRotTile + 4];
+  __shared__ uint32_t tile[kRotTile * kRotStride];
   uint32_t b = blockIdx.x;
   const uint32_t f = b / (a.tiles_x * a.tiles_y);
   b -= f * a.tiles_x * a.tiles_y;
@@ -369,42 +386,55 @@ __global__ __launch_bounds__(kBlock) void k_rotate_cw(const RotateArgs a) {
   const uint8_t *src = a.src + uint64_t(f) * a.src_frame_stride;
   uint8_t *dst = a.dst + uint64_t(f) * a.dst_frame_stride;
   const int cols = int(a.cols), rows = int(a.rows);
-  const int q = int(threadIdx.x & 15u) * 4, p = int(threadIdx.x >> 4);  // 16 dword columns x 16 rows per pass
-
+  {  // rows in: thread (lr, lc) takes dword column lc of the rows lr, lr + 8, ...
+    const int lc = int(threadIdx.x & 31u), lr = int(threadIdx.x >> 5);
+    const int x = c0 + 4 * lc;
+    uint32_t v[kRotTile / 8];
 #pragma unroll
-  for (int k = 0; k < kRotTile / 16; ++k) {
-    const int r = p + 16 * k, y = r0 + r, x = c0 + q;
-    uint32_t v = 0;
-    if (y < rows) {
-      const uint8_t *row = src + uint64_t(y) * a.src_pitch;
-      if (x + 3 < cols) {
-        __builtin_memcpy(&v, row + x, 4);
-      } else {
+    for (int k = 0; k < kRotTile / 8; ++k) {
+      const int y = r0 + lr + 8 * k;
+      v[k] = 0;
+      if (y < rows) {
+        const uint8_t *row = src + uint64_t(y) * a.src_pitch;
+        if (x + 3 < cols) {
+          __builtin_memcpy(&v[k], row + x, 4);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (x + i < cols) v |= uint32_t(row[x + i]) << (8 * i);
+          for (int i = 0; i < 4; ++i)
+            if (x + i < cols) v[k] |= uint32_t(row[x + i]) << (8 * i);
+        }
       }
     }
-    __builtin_memcpy(&tile[r][q], &v, 4);
+#pragma unroll
+    for (int k = 0; k < kRotTile / 8; ++k) tile[(lr + 8 * k) * kRotStride + lc] = v[k];
   }
   __syncthreads();
-  // destination tile: rows c0 .. c0+63 (source columns), columns rows-1-(r0+63) .. rows-1-r0
+  // destination tile: rows c0 .. c0+127 (source columns); source row r0 + l lands in column j0 + 127 - l
   const int j0 = rows - 1 - (r0 + kRotTile - 1);
+  const int rg = int(threadIdx.x & 7u), cd = int(threadIdx.x >> 3);
+  uint32_t w[16];
 #pragma unroll
-  for (int k = 0; k < kRotTile / 16; ++k) {
-    const int i = p + 16 * k;  // destination row inside the tile = source column
-    if (c0 + i >= cols) continue;
-    uint32_t v = 0;
+  for (int k = 0; k < 16; ++k) w[k] = tile[(16 * rg + k) * kRotStride + cd];
+  uint32_t o[4][4];  // o[c][d]: dword d of the 16 bytes of destination row 4 cd + c
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v |= uint32_t(tile[kRotTile - 1 - (q + t)][i]) << (8 * t);
-    uint8_t *row = dst + uint64_t(c0 + i) * a.dst_pitch;
-    const int j = j0 + q;  // destination column of byte 0 (negative for the rows past the image end)
+  for (int d = 0; d < 4; ++d) {
+    uint32_t t[4];
+    rot_transpose_4x4(w[15 - 4 * d], w[14 - 4 * d], w[13 - 4 * d], w[12 - 4 * d], t);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c][d] = t[c];
+  }
+  const int j = j0 + kRotTile - 16 - 16 * rg;  // destination column of the thread's first byte (< 0: past the image end)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int i = c0 + 4 * cd + c;  // destination row = source column
+    if (i >= cols) continue;
+    uint8_t *row = dst + uint64_t(i) * a.dst_pitch;
     if (j >= 0) {
-      __builtin_memcpy(row + j, &v, 4);
+      __builtin_memcpy(row + j, o[c], 16);
     } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (j + t >= 0) row[j + t] = uint8_t(v >> (8 * t));
+      for (int t = 0; t < 16; ++t)
+        if (j + t >= 0) row[j + t] = uint8_t(o[c][t >> 2] >> (8 * (t & 3)));
     }
   }
 }
