@@ -88,13 +88,18 @@ def test_batch_u8_native_geometry():
         assert_points_close(pts, wp, max_ulp=1)
 
 
-def test_compact_is_idempotent_and_sorted_at_full_size():
+@pytest.mark.parametrize("form,general", [(0, 0), (24, 0), (4, 0), (24, 1), (4, 1)])
+def test_compact_is_idempotent_and_sorted_at_full_size(form, general):
     """Size-independent properties at 4K: indices strictly increasing; the
     points gathered by those indices from a PARITY run equal the COMPACT
-    points bit-for-bit; counts equal the number of finite PARITY points."""
-    q = d2pc.make_q()
+    points bit-for-bit; counts equal the number of finite PARITY points.  In every reprojection form
+    (d2pc_set_reproject_form) and on both of its routes (specialised kinds / general kernel)."""
+    q = d2pc.make_q(cx=1919.37, cy=1079.61, nx=3840, ny=2160)   # a fractional principal point: 2.4's column sum rounds
     frames = [synth_disparity(4, 20, 3840, 2160, "holes")]
     with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as c, d2pc.Context(q=q) as p:
+        for ctx in (c, p):
+            ctx.set_reproject_form(form)
+            ctx.set_tuning("force_general_q", general)
         bc = _batch(c, frames, want_index=True)
         bp = _batch(p, frames, want_index=False)
         bc.launch()
