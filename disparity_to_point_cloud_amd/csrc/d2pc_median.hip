@@ -97,12 +97,12 @@ __global__ __launch_bounds__(kBlock) void k_mono16_to_mono8(const uint8_t *__res
 
 hipError_t launch_mono16_to_mono8(const void *src, void *dst, const MedianArgs &a, hipStream_t stream) {
   const uint32_t groups = (a.width + 7u) / 8u;
-  if (groups == 0 || a.height == 0 || a.n_frames == 0 || a.height > 65535u) return hipErrorInvalidValue;
+  if (groups == 0 || a.height == 0 || a.n_frames == 0) return hipErrorInvalidValue;
   const uint32_t frames = a.n_frames < 65535u ? a.n_frames : 65535u;
   const uint8_t *s8 = static_cast<const uint8_t *>(src);
   uint8_t *d8 = static_cast<uint8_t *>(dst);
   const uint32_t waves = (groups + 63u) / 64u;
-  if (groups * 10u >= waves * 64u * 9u) {  // rows fill their waves: the division-free grid
+  if (groups * 10u >= waves * 64u * 9u && a.height <= 65535u) {  // rows fill their waves: the division-free grid
     const uint32_t block = waves * 64u < uint32_t(kBlock) ? waves * 64u : uint32_t(kBlock);
     hipLaunchKernelGGL(k_mono16_to_mono8<true>, dim3((groups + block - 1) / block, a.height, frames), dim3(block), 0, stream, s8, d8, a);
   } else {

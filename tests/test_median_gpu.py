@@ -172,6 +172,21 @@ def test_mono16_to_mono8_device_matches_oracle(w, h):
             ctx.mono16_to_mono8_device(src.data_ptr(), w, h, 2 * w, 0, 1, src.data_ptr(), w, 0)
 
 
+def test_mono16_to_mono8_device_on_degenerate_shapes():
+    """Both index forms of the rescale kernel (a grid of rows / one flat index per frame) at their limits: more rows
+    than a grid dimension holds, rows of one pixel, rows that fill whole waves exactly."""
+    rng = np.random.default_rng(16)
+    for h, w in ((70000, 512), (70000, 9), (3, 1), (5, 4096), (1, 65535)):
+        img = rng.integers(0, 65536, size=(h, w)).astype(np.uint16)
+        src = torch.from_numpy(img.view(np.int16)).cuda()
+        dst = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+        with d2pc.Context(q=d2pc.make_q()) as ctx:
+            ctx.mono16_to_mono8_device(src.data_ptr(), w, h, 2 * w, 2 * w * h, 1, dst.data_ptr(), w, w * h,
+                                       torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), oracle.mono16_to_mono8(img)), (h, w)
+
+
 @pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
 @pytest.mark.parametrize("k", [0, 11])
 def test_process_mono16_is_the_whole_callback(mode, k):
