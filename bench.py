@@ -133,27 +133,54 @@ def algorithmic_bytes(batch, n_points, with_index):
     return 4 * r_in + (20 if with_index else 16) * n_points
 
 
-def timed_steps(batch, steps, warmup, dist_sync):
-    """`batch` only needs a launch() method (one pass of the hot path, asynchronous)."""
-    for _ in range(warmup):
+def timed_steps(batch, steps, warmup, dist_sync, heat_ms=60.0, first_n=20):
+    """The contract's measurement: W untimed warm-up steps, then EXACTLY K timed steps between barrier +
+    synchronize pairs.  `batch` only needs a launch() method (one pass of the hot path, asynchronous).
+
+    The warm-up has a TIME floor as well as a count: after the W steps the same launch is repeated (untimed) until
+    >= heat_ms of device time have passed since the device was last idle.  After seconds of idleness (frames generated
+    on the CPU) this device needs ~25 ms of back-to-back launches to reach its steady clock, and launches 6-25 after an
+    idle period run 8-10 % slow (profiles/r03_warmup_ramp.txt, r03_idle_ramp.txt): `--warmup 5 --steps 20` alone
+    times exactly that window.  The short gap of the barrier + synchronize in front of the timed region does not
+    restart the ramp (r03_idle_ramp.txt, idle <= 0.5 ms).  Returns (wall s, ms per launch over the K steps,
+    ms per launch over the first min(first_n, K) of them, warm-up launches actually made, their device ms)."""
+    h = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    h[0].record()
+    n_probe = max(warmup, 2)
+    for _ in range(n_probe):
         batch.launch()
+    h[1].record()
     torch.cuda.synchronize()
+    spent = h[0].elapsed_time(h[1])
+    per = max(spent / n_probe, 1e-3)
+    extra = int(min(20000, max(0.0, heat_ms - spent) / per + 0.999)) if heat_ms > 0 else 0
+    for _ in range(extra):
+        batch.launch()
+    h[2].record()
+    torch.cuda.synchronize()
+    warm_ms = h[0].elapsed_time(h[2])
     # ONE pair of HIP events around the K launches, recorded on the stream the
     # kernels are launched on: average launch duration = elapsed / K (includes
     # the ~1-2 us gaps between back-to-back launches, so it is an upper bound;
-    # per-step event pairs add a marker packet per launch and inflate it).
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # per-step event pairs add a marker packet per launch and inflate it).  One
+    # more marker after the first `first_n` launches when K is larger than that.
+    e0, e1, em = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    k_first = min(first_n, steps)
     dist_sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(steps):
+    for i in range(steps):
         batch.launch()
+        if i + 1 == k_first and k_first < steps:
+            em.record()
     e1.record()
     torch.cuda.synchronize()
     dist_sync()
     t1 = time.perf_counter()
-    return t1 - t0, e0.elapsed_time(e1) / steps
+    ms = e0.elapsed_time(e1) / steps
+    ms_first = e0.elapsed_time(em) / k_first if k_first < steps else ms
+    return t1 - t0, ms, ms_first, n_probe + extra, warm_ms
 
 
 def timed_rounds(batch, n, warmup=2, floor_ms=100.0, min_rounds=5, max_rounds=400, heat_ms=30.0):
@@ -368,6 +395,9 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="frames per step (ring size)")
     ap.add_argument("--border", type=int, default=40, help="ROI inset (reference: 40)")
     ap.add_argument("--mode", choices=["parity", "compact"], default="parity")
+    ap.add_argument("--heat-ms", type=float, default=60.0,
+                    help="time floor of the warm-up: after the W warm-up steps the same launch is repeated, untimed, until "
+                         "this much device time has passed (0 = warm up by count only)")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -432,10 +462,11 @@ def main():
     torch.cuda.synchronize()
     n_points = int(batch.counts.sum().item())
 
-    # The contract's measurement: W warm-up steps, then K timed steps between barriers.  What the device did before
-    # moves it by several per cent (clock management: profiles/r03_warmup_ramp.txt, r03_idle_ramp.txt) -- nothing is
-    # done about that here; the rounds after it (kernel_ms_spread) show the sustained time of the same launch.
-    wall, kernel_ms = timed_steps(batch, a.steps, a.warmup, multi_gpu.barrier)
+    # The contract's measurement: W warm-up steps (with a time floor: >= --heat-ms of device time since the last idle
+    # point, see timed_steps), then K timed steps between barriers.  The rounds after it (kernel_ms_sustained_median)
+    # show the sustained time of the same launch; frac and frac_sustained should agree within ~2 %.
+    wall, kernel_ms, kernel_ms_first, warm_n, warm_ms = timed_steps(batch, a.steps, a.warmup, multi_gpu.barrier,
+                                                                    heat_ms=a.heat_ms)
     # every rank calibrates its device on its own output buffer (plain fill / copy, >= 100 ms each)
     cal = device_calibration(ctx, batch) if not a.no_extras else None
     wall = multi_gpu.allreduce_max(wall)
@@ -476,6 +507,10 @@ def main():
             "kernel_ms_avg_max_over_ranks": round(kernel_ms_max, 4),
             "kernel_ms_avg_per_rank": [round(x, 4) for x in per_rank_kernel_ms],
             "read_component_GBs": round(4 * a.frames * batch.roi_n / (kernel_ms * 1e-3) / 1e9, 1),
+            # the first min(20, K) launches of the timed region on their own (what `--steps 20` samples)
+            "frac_first_20": round(alg / (kernel_ms_first * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel_ms_first_20": round(kernel_ms_first, 4),
+            "warmup_launches_actual": warm_n, "warmup_ms_actual": round(warm_ms, 2), "warmup_heat_floor_ms": a.heat_ms,
         },
     }
     fills = multi_gpu.allgather_floats(cal["device_fill_GBs"] if cal else 0.0)
@@ -487,6 +522,11 @@ def main():
         # launches until >= 100 ms), next to what the device gives a plain fill / copy
         sp = spread(timed_rounds(batch, a.steps, 0))
         out["roofline"]["kernel_ms_spread"] = sp
+        # scalars (nested objects do not survive the driver's parser): the sustained time of the same launch
+        out["roofline"]["kernel_ms_sustained_median"] = sp["median"]
+        out["roofline"]["kernel_ms_sustained_min"] = sp["min"]
+        out["roofline"]["kernel_ms_sustained_max"] = sp["max"]
+        out["roofline"]["frac_sustained"] = round(alg / (sp["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out["roofline"]["frac_at_min_median_max_ms"] = [round(alg / (sp[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                         for k in ("min", "median", "max")]
         out["roofline"].update(cal)

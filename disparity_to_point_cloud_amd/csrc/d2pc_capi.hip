@@ -81,6 +81,9 @@ struct d2pc_ctx {
   int parity_small = 0;          // PARITY kernel form: 0 = choose, 1 = one-shot blocks of 256 * pxt pixels (pxt 1, 2, 4), 2 = tiles walked by fewer blocks
   int blocks_per_cu = 128;
   int onepass_blocks_per_cu = 0;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each: 4 fit); 0 = choose per launch
+  int big_batch_algo = 4;          // COMPACT launches of >= 4 frames and >= 24,576 tiles: 4 = chunked two-pass of one-shot blocks, 2 = single pass
+  int chunk_mb = 96;               // algo 4: input bytes per chunk (MiB); the chunk must stay in the 256 MiB Infinity Cache for one launch
+  int chunk_first_frames = 0;      // algo 4: frames of the first chunk (0 = an eighth of a chunk)
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
   int general_q_form = 0;        // 0: OpenCV 3/4's association bit for bit; 1: fused multiply-adds (round 2's form)
@@ -251,6 +254,17 @@ int make_geom(d2pc_ctx *ctx, int dtype, float scale, int width, int height, size
   g->spin_ticks = uint32_t(ctx->spin_timeout_ms) * kSpinTicksPerMs;
   g->pxt = uint32_t(pxt);
   return D2PC_OK;
+}
+
+// The same frames cut into tiles of 256 * pxt ROI pixels.
+void retile(Geom *g, int pxt) {
+  const uint32_t tile_px = uint32_t(kBlock) * uint32_t(pxt);
+  g->tiles_per_frame = (g->roi_n + tile_px - 1) / tile_px;
+  g->total_tiles = uint32_t(uint64_t(g->tiles_per_frame) * g->n_frames);
+  g->groups_per_frame = (g->tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
+  g->frame_state_stride = frame_state_stride(g->tiles_per_frame);
+  g->div_tpf = make_fastdiv(g->tiles_per_frame ? g->tiles_per_frame : 1u);
+  g->pxt = uint32_t(pxt);
 }
 
 // Is `s` capturing, and if so which capture?
@@ -445,7 +459,9 @@ int fill_q(d2pc_ctx *ctx, LaunchArgs &a, int width) {
     sg.n = 1;
     sg.x[0] = 0;
     sg.c[0] = s;
-    const uint32_t cols = uint32_t(width) < 4096u ? 4096u : uint32_t(width);
+    // (only the columns this launch has: a small non-dyadic principal point crosses one binade per doubling of the
+    // column, and a table replayed over 4096 columns whatever the width refused Qs that a narrow frame can serve)
+    const uint32_t cols = uint32_t(width);
     for (uint32_t x = 1; x < cols; ++x) {
       s = s + q[0];
       const double c = s - double(x);
@@ -525,9 +541,29 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   // is being captured (its epoch argument would freeze in the graph); one 1080p frame 16 -> ~8 us
   const bool resident_ok = g.total_tiles <= uint32_t(ctx->cu_count * kResidentBlocksPerCu) && g.tiles_per_frame <= 1024u &&
                            !capture_info(stream, nullptr);
-  const int dflt = big_batch ? 2 : resident_ok ? 3 : 1;
+  const int dflt = big_batch ? ctx->big_batch_algo : resident_ok ? 3 : 1;
   a.compact_algo = force_algo ? force_algo : ctx->cfg.compact_algo ? ctx->cfg.compact_algo : dflt;
-  if (a.compact_algo == 3 && !resident_ok) a.compact_algo = big_batch ? 2 : 1;  // (asked for, not possible here)
+  if (a.compact_algo == 3 && !resident_ok) a.compact_algo = big_batch ? ctx->big_batch_algo : 1;  // (asked for, not possible here)
+  if (a.compact_algo == 4) {
+    // chunked two-pass (k_compact_chunk): the geometry in its own 512-pixel tiles; chunks of whole frames whose input
+    // stays in the Infinity Cache between the launch that counts it and the launch that scatters it
+    if (g.roi_n == 0) return fail(ctx, D2PC_ERR_INTERNAL, "empty ROI reached the compaction launch");
+    Geom g4 = g;
+    retile(&g4, 2);
+    if (uint64_t(g4.tiles_per_frame) * g4.n_frames > 0x7fffffffull) return fail(ctx, D2PC_ERR_BAD_SIZE, "batch too large");
+    uint32_t gw = 0;
+    g4.frame_state_stride = chunk_frame_state_stride(g4.tiles_per_frame, &gw);
+    a.geom = g4;
+    a.pxt = 2;
+    const uint64_t frame_bytes = uint64_t(g.roi_n) * elem_size(dtype);
+    uint64_t per = (uint64_t(ctx->chunk_mb) << 20) / (frame_bytes ? frame_bytes : 1);
+    if (per < 1) per = 1;
+    if (per > g.n_frames) per = g.n_frames;
+    a.chunk_frames = uint32_t(per);
+    // the first chunk is counted with nothing to run beside it: an eighth of a chunk (a 4K stream: one frame)
+    a.chunk_first = ctx->chunk_first_frames > 0 ? uint32_t(ctx->chunk_first_frames) : uint32_t((per + 7) / 8);
+    if (a.chunk_first > a.chunk_frames) a.chunk_first = a.chunk_frames;
+  }
   if (a.compact_algo == 2) {
     // the single-pass kernel is software-pipelined over a block's tiles: it
     // wants few, long-lived blocks (about what is resident), not many short ones
@@ -543,7 +579,9 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     a.epoch = ctx->resident_epoch++;
     if (ctx->resident_epoch >= kEpochEnd) {  // (once in 2^30 launches: start over from clean state)
       ctx->resident_epoch = kEpochBase;
-      for (StateBuf *b : ctx->states.bufs)
+      std::vector<StateBuf *> all(ctx->states.bufs);
+      for (PipeSlot &sl : ctx->slots) all.push_back(&sl.st);  // the pipeline slots' own state buffers carry epochs too
+      for (StateBuf *b : all)
         if (b->p) {
           if (b->pending) D2PC_HIP(ctx, hipEventSynchronize(b->done));
           D2PC_HIP(ctx, hipMemsetAsync(b->p, 0, b->cap, nullptr));
@@ -557,7 +595,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     a.grid = g.total_tiles < want2 ? g.total_tiles : want2;
     if (a.grid == 0) a.grid = 1;
   }
-  a.state_bytes = compact_state_bytes(g);
+  a.state_bytes = compact_state_bytes(a.geom);
   a.stats = ctx->d_stats;
   StateBuf *sb = nullptr;
   int st = acquire_buf(ctx, ctx->states, stream, a.state_bytes, 0, fixed_state, &sb);
@@ -734,7 +772,7 @@ int d2pc_create(const d2pc_config *cfg, d2pc_ctx **out) {
   if (cfg->struct_size != sizeof(d2pc_config)) return D2PC_ERR_INVALID_ARG;
   if (cfg->border < 0 || cfg->border > 16384) return D2PC_ERR_INVALID_ARG;
   if (cfg->mode != D2PC_MODE_PARITY && cfg->mode != D2PC_MODE_COMPACT) return D2PC_ERR_INVALID_ARG;
-  if (cfg->compact_algo < 0 || cfg->compact_algo > 3) return D2PC_ERR_INVALID_ARG;
+  if (cfg->compact_algo < 0 || cfg->compact_algo > 4) return D2PC_ERR_INVALID_ARG;
   if (std::isnan(cfg->min_disparity)) return D2PC_ERR_INVALID_ARG;
   int n = d2pc_device_count();
   if (n <= 0 || cfg->device_id < 0 || cfg->device_id >= n) return D2PC_ERR_NO_DEVICE;
@@ -945,6 +983,9 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
+  else if (!strcmp(key, "big_batch_algo") && (value == 2 || value == 4)) ctx->big_batch_algo = value;
+  else if (!strcmp(key, "chunk_mb") && value >= 1 && value <= 4096) ctx->chunk_mb = value;
+  else if (!strcmp(key, "chunk_first_frames") && value >= 0 && value <= 65535) ctx->chunk_first_frames = value;
   else if (!strcmp(key, "callback_chunks") && value >= 0 && value <= 64) ctx->cb_chunks = value;
   else if (!strcmp(key, "callback_fused") && (value == 0 || value == 1)) ctx->cb_fused = value;
   else if (!strcmp(key, "callback_fused_compact") && value >= 0 && value <= 2) ctx->cb_fused_compact = value;
@@ -1537,31 +1578,54 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
         if ((st = fill_q(ctx, a, width)) != D2PC_OK) return st;
         a.qs.w_safe = w_safe_for(ctx, g);
         if (compact) {  // the COMPACT form hands row counts over between the tiles of a band: its own state
-          uint32_t stride = 0;
-          a.state_bytes = callback_compact_state_bytes((g.roi_w + 255u) / 256u, (g.roi_n / g.roi_w + 31u) / 32u, uint32_t(nf), &stride);
-          g.frame_state_stride = stride;
-          a.stats = ctx->d_stats;
-          StateBuf *sb = nullptr;
-          if ((st = acquire_buf(ctx, ctx->states, sr, a.state_bytes, 0, nullptr, &sb)) != D2PC_OK) return st;
-          a.state = sb->p;
-          sb->algo = 2;  // its header carries the hand-off's timeout flag, like the single pass's
-          a.geom = g;
-          a.compact_algo = 1;
-          if (ctx->cb_fused_compact == 2) {
-            // persistent blocks, a multiple of the frame count; every frame needs more blocks than a band has tiles
-            // (or as many as it has tiles): otherwise the one-tile-per-block form serves the launch
-            const uint32_t tiles_x = (g.roi_w + 255u) / 256u, tpf = tiles_x * ((g.roi_n / g.roi_w + 31u) / 32u);
-            uint32_t per_frame = uint32_t(ctx->cu_count * ctx->cb_pipe_blocks_per_cu) / uint32_t(nf);
-            if (per_frame > tpf) per_frame = tpf;
-            if (per_frame > tiles_x || per_frame == tpf) {
-              a.grid = per_frame * uint32_t(nf);
-              a.compact_algo = 2;
+          // Residency.  Both forms of the kernel hand counts over between the tiles of a BAND, and a frame's blocks are
+          // dispatched round-robin over the launch's frames (frame = blockIdx % n_frames): a frame needs tiles_x of its
+          // own blocks resident at once, or no frame ever finishes band 0 (advisor, round 3: from ~385 frames of 752x480
+          // or ~55 frames of 4K every wave span out its 4-s budget).  A call with more frames than that is cut into
+          // sub-batches of nfc frames with resident / nfc > tiles_x, launched back to back on the same stream (they share
+          // the stream's state buffer: a sub-batch's zeroing kernel runs behind the previous sub-batch's last store).
+          const uint32_t tiles_x = (g.roi_w + 255u) / 256u, tiles_y = (g.roi_n / g.roi_w + 31u) / 32u, tpf = tiles_x * tiles_y;
+          const uint32_t resident = uint32_t(ctx->cu_count * (ctx->cb_pipe_blocks_per_cu < 3 ? ctx->cb_pipe_blocks_per_cu : 3));  // (LDS and registers admit 3 per CU)
+          uint32_t nfc = resident / (tiles_x + 1u);  // (tiles_x <= kCbMaxTilesX = 128 < resident: nfc >= 1 on any device of >= 43 CUs)
+          if (nfc == 0) nfc = 1;
+          for (int s0 = 0; s0 < nf; s0 += int(nfc)) {
+            const int ns = nf - s0 < int(nfc) ? nf - s0 : int(nfc);
+            Geom gs;
+            if ((st = make_geom(ctx, D2PC_DTYPE_U8, scale, width, height, kin_pitch, kin_frame, ns, out_frame_stride, pxt, &gs)) != D2PC_OK)
+              return st;
+            LaunchArgs as = a;
+            MedianArgs ms = m;
+            ms.n_frames = uint32_t(ns);
+            as.out_points = static_cast<uint8_t *>(a.out_points) + size_t(s0) * out_frame_stride * 16;
+            as.out_index = a.out_index ? a.out_index + size_t(s0) * out_frame_stride : nullptr;
+            as.counts = a.counts + s0;
+            uint32_t stride = 0;
+            as.state_bytes = callback_compact_state_bytes(tiles_x, tiles_y, uint32_t(ns), &stride);
+            gs.frame_state_stride = stride;
+            as.stats = ctx->d_stats;
+            StateBuf *sb = nullptr;
+            if ((st = acquire_buf(ctx, ctx->states, sr, as.state_bytes, 0, nullptr, &sb)) != D2PC_OK) return st;
+            as.state = sb->p;
+            sb->algo = 2;  // its header carries the hand-off's timeout flag, like the single pass's
+            as.geom = gs;
+            as.compact_algo = 1;
+            if (ctx->cb_fused_compact == 2) {
+              // persistent blocks, a multiple of the frame count; every frame needs more blocks than a band has tiles
+              // (or as many as it has tiles): otherwise the one-tile-per-block form serves the launch
+              uint32_t per_frame = resident / uint32_t(ns);
+              if (per_frame > tpf) per_frame = tpf;
+              if (per_frame > tiles_x || per_frame == tpf) {
+                as.grid = per_frame * uint32_t(ns);
+                as.compact_algo = 2;
+              }
             }
-          }
-          D2PC_HIP(ctx, launch_callback_bs_compact(a, m, kin, median_ksize));
-          if (!sb->captured) {
-            D2PC_HIP(ctx, hipEventRecord(sb->done, sr));
-            sb->pending = true;
+            // (the one-tile-per-block form: ns * tiles_x <= resident - ns by the choice of nfc, so every frame has a whole
+            // band of blocks resident from the first dispatch round on)
+            D2PC_HIP(ctx, launch_callback_bs_compact(as, ms, static_cast<const uint8_t *>(kin) + size_t(s0) * kin_frame, median_ksize));
+            if (!sb->captured) {
+              D2PC_HIP(ctx, hipEventRecord(sb->done, sr));
+              sb->pending = true;
+            }
           }
           continue;
         }

@@ -59,7 +59,21 @@ struct Geom {
   uint32_t pxt;                       // ROI pixels per thread the tile counts above were formed with (host side)
 };
 
-constexpr int kQxSegs = 7;  // binades a 2.4-style running sum may cross inside one image row (2^9 .. 2^15 for |cx| < 512)
+// Binades a 2.4-style running sum may cross inside one image row: one per doubling of the column for a small principal
+// point (q03 = -0.1: 2^-1 .. 2^15 over 2^15 columns), 7 for the usual |cx| of a few hundred.  The kernels stop at the
+// table's length `n` (wave-uniform), so the usual case pays for its own segments only.
+constexpr int kQxSegs = 18;
+
+// One launch of the chunked two-pass compaction (k_compact_chunk, compact_algo 4): which frames its scatter blocks
+// serve, which frames its count blocks serve, and how the two kinds are interleaved in the grid.
+struct ChunkArgs {
+  uint32_t scatter_f0, scatter_tiles;  // frames from scatter_f0 on: scatter_tiles = frames x tiles_per_frame one-shot blocks
+  uint32_t count_f0, count_blocks;     // frames from count_f0 on: count_blocks = frames x groups_per_frame
+  uint32_t period;                     // blocks 0, P, 2P, ... are count blocks while they last (grid = scatter_tiles + count_blocks)
+  uint32_t groups_per_frame;           // ceil(tiles_per_frame / 32)
+  uint32_t gsum_words;                 // words of a frame's state ahead of its tile counts (the group totals, padded)
+  FastDiv div_gpf, div_period;
+};
 
 // OpenCV 2.4's running column sum qx (per row qx = q01*y + q03, then qx += q00 per column, one rounding per step)
 // as the host replayed it for one (Q, width): columns [x[j], x[j+1]) have qx(u) = double(u) + c[j] EXACTLY.

@@ -54,6 +54,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifndef D2PC_SCATTER_STORE_NT
 #define D2PC_SCATTER_STORE_NT 1
 #endif
+// chunked two-pass (compact_algo 4): point and index stores of its one-shot scatter blocks
+#ifndef D2PC_CHUNK_STORE_NT
+#define D2PC_CHUNK_STORE_NT 1
+#endif
+#ifndef D2PC_CHUNK_INDEX_NT
+#define D2PC_CHUNK_INDEX_NT 0
+#endif
 #ifndef D2PC_CLEAR_WITH_MEMSET
 #define D2PC_CLEAR_WITH_MEMSET 0
 #endif
@@ -135,8 +142,10 @@ struct QArg<QK_STEREO_CV4> {
 __device__ __forceinline__ double qx_offset(const QxSegs &sg, uint32_t u) {
   double c = sg.c[0];
 #pragma unroll
-  for (int j = 1; j < kQxSegs; ++j)
-    if (uint32_t(j) < sg.n && u >= sg.x[j]) c = sg.c[j];
+  for (int j = 1; j < kQxSegs; ++j) {
+    if (uint32_t(j) >= sg.n) break;  // (wave-uniform: a scalar branch)
+    if (u >= sg.x[j]) c = sg.c[j];
+  }
   return c;
 }
 
@@ -208,8 +217,8 @@ __device__ __forceinline__ void reproject(const QArg<QK_GENERAL> &A, uint32_t u,
 // W and the numerators of the kind's OpenCV generation (d2pc_device.hpp).
 template <int QK>
 __device__ __forceinline__ double stereo_w(const QArg<QK> &A, double dd) {
-  if constexpr (is_stereo(QK)) {
-    return fma(A.s.a, dd, A.s.b);
+  if constexpr (QK == QK_STEREO) {
+    return fma(A.s.a, dd, A.s.b);  // the default kind: one rounding
   } else {
 #pragma clang fp contract(off)
     const double t = A.s.a * dd;  // both generations round the product and the sum apart
@@ -1043,9 +1052,12 @@ __global__ __launch_bounds__(kBlock) void k_compact_resident(const uint8_t *__re
     sum = wave_sum(sum);
     if (lane == 0) {
       s_prefix = sum;
-      if (lt == g.tiles_per_frame - 1u)
-        __hip_atomic_store(counts + f, gave_up ? kCountTimedOut : sum + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if (gave_up)
+      if (lt == g.tiles_per_frame - 1u) {
+        // a tile of this launch that gave up earlier (and scattered with a partial prefix) must not be papered over by
+        // a last tile whose own timer had not run out yet: the flag carries the epoch of the launch that broke
+        const bool broken = gave_up || __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+        __hip_atomic_store(counts + f, broken ? kCountTimedOut : sum + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (gave_up)
         __hip_atomic_store(counts + f, kCountTimedOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if D2PC_ONEPASS_STATS
       if (spins) {
@@ -1064,6 +1076,206 @@ __global__ __launch_bounds__(kBlock) void k_compact_resident(const uint8_t *__re
   float4 *fout = out + uint64_t(f) * g.out_frame_stride;
   uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
   tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, s_prefix, excl, wave, lane, g.roi_n);
+}
+
+// --------------------------------------------------------------------------
+// K2c: CHUNKED two-pass compaction (compact_algo 4) for big batches: one-shot blocks only, no hand-off inside a launch.
+//
+// The batch is cut into chunks of whole frames whose input fits the 256 MiB Infinity Cache (the host aims at <= ~100 MB),
+// and launch i does two things at once, in ONE grid of short-lived blocks:
+//   * SCATTER blocks (one per 512 ROI pixels of chunk i, two pixels per thread -- the PARITY headline kernel's shape):
+//     the points of the tile, ballots, the ordered stores.  The tile's output position is known when the block starts:
+//     the counts of chunk i were left by launch i-1, so there is no ticket, no poll and no long-lived block -- the two
+//     things DESIGN section 9 blames for the single pass's distance from PARITY.  The disparities were read by launch
+//     i-1's count blocks ~one launch ago and come from the Infinity Cache, not from HBM.
+//   * COUNT blocks (one per group of 32 tiles of chunk i+1, interleaved every `period`-th block): the exact validity
+//     predicate over 16,384 pixels read 16 B per lane, one count per tile and one total per group, plain stores.
+//     Nothing in the same launch reads them.  Their HBM reads are the only reads of the launch that go to HBM, so a
+//     launch moves the bytes of a PARITY launch over the same frames.
+// Prefix of a tile = totals of the frame's groups before its own + counts of the tiles before it in its group: <= 2
+// dword loads per thread for a 4K frame (478 groups), summed through LDS together with the cell counts -- one barrier.
+// Every state word that is read was written by the previous launch of the same call: nothing to zero, no epochs,
+// capturable.  Launch 0 only counts (chunk 0, kept short by the host: one frame), the last launch only scatters.
+// --------------------------------------------------------------------------
+constexpr uint32_t kChunkGroupShift = 5, kChunkGroupTiles = 1u << kChunkGroupShift;  // tiles per count block
+constexpr int kChunkS = 2;                                                           // pixels per thread of a scatter block
+constexpr uint32_t kChunkTile = uint32_t(kBlock) * kChunkS;                          // 512 pixels
+
+struct ChunkFrameState {
+  uint32_t *gsum, *tcnt;  // group totals; tile counts
+  __device__ __forceinline__ ChunkFrameState(uint8_t *state, const Geom &g, const ChunkArgs &c, uint32_t f) {
+    gsum = reinterpret_cast<uint32_t *>(state + sizeof(StateHeader) + uint64_t(f) * g.frame_state_stride);
+    tcnt = gsum + c.gsum_words;
+  }
+};
+
+// validity of the pixel (image coordinates uu, vv; disparity d) exactly as the scatter blocks decide it
+template <int QK>
+__device__ __forceinline__ bool chunk_pixel_valid(const QArg<QK> &Q, const Geom &g, uint32_t uu, uint32_t vv, float d) {
+  if constexpr (is_stereo(QK)) {
+    return stereo_point_valid(Q, uu, vv, d, g.min_disparity);
+  } else {
+    float X, Y, Z;
+    reproject(Q, uu, vv, d, X, Y, Z);
+    return point_is_valid(X, Y, Z, d, g.min_disparity);
+  }
+}
+
+template <int DT, int QK, bool VEC>
+__device__ __forceinline__ void chunk_count_block(const uint8_t *__restrict__ disp, uint8_t *state, const Geom &g,
+                                                  const QArg<QK> &Q, const ChunkArgs &c, uint32_t cb, uint32_t *s_red) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fl = fdiv(cb, c.div_gpf);
+  const uint32_t grp = cb - fl * c.groups_per_frame;
+  const uint32_t f = c.count_f0 + fl;
+  const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
+  const ChunkFrameState fs(state, g, c, f);
+  constexpr uint32_t kWaveTiles = kChunkGroupTiles / 4u;  // 8 tiles = 4096 pixels per wave
+  const uint32_t tile0 = grp * kChunkGroupTiles + wave * kWaveTiles;
+  uint32_t mine = 0;   // lane m < 8: the count of the wave's tile m
+  uint32_t total = 0;  // wave-uniform
+  if constexpr (VEC) {
+    // 16 pieces of 1 KiB per wave, all requested before the first is looked at
+    constexpr int NP = int(kWaveTiles) * 2;
+    v4f q[NP];
+    uint32_t uu[NP], vv[NP];
+    const uint32_t i00 = tile0 * kChunkTile + lane * 4u;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const uint32_t i0 = i00 + uint32_t(j) * 256u;
+      const uint32_t v = fdiv(i0, g.div_roi_w);
+      uu[j] = i0 - v * g.roi_w + g.border;
+      vv[j] = v + g.border;
+      const uint32_t off = vv[j] * g.row_stride + uu[j] * 4u;
+      const uint32_t last4 = g.last_off - 12u;  // the frame's last aligned group (tails load in bounds and count nothing)
+      q[j] = ld(reinterpret_cast<const v4f *>(fin + (off < last4 ? off : last4)));
+    }
+#pragma unroll
+    for (int m = 0; m < int(kWaveTiles); ++m) {
+      uint32_t ct = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * m + h;
+        const uint32_t i0 = i00 + uint32_t(j) * 256u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = (i0 + uint32_t(e) < g.roi_n) && chunk_pixel_valid<QK>(Q, g, uu[j] + uint32_t(e), vv[j], q[j][e]);
+          ct += uint32_t(__popcll(__ballot(ok)));
+        }
+      }
+      mine = lane == uint32_t(m) ? ct : mine;
+      total += ct;
+    }
+  } else {
+    // one element per lane and load: eight loads per tile, a tile at a time
+    for (uint32_t m = 0; m < kWaveTiles; ++m) {
+      const uint32_t i00 = (tile0 + m) * kChunkTile + lane;
+      float d[8];
+      uint32_t uu[8], vv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t i = i00 + uint32_t(j) * 64u;
+        const uint32_t v = fdiv(i, g.div_roi_w);
+        uu[j] = i - v * g.roi_w + g.border;
+        vv[j] = v + g.border;
+        const uint32_t off = vv[j] * g.row_stride + uu[j] * elem_bytes<DT>();
+        d[j] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
+      }
+      uint32_t ct = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = (i00 + uint32_t(j) * 64u < g.roi_n) && chunk_pixel_valid<QK>(Q, g, uu[j], vv[j], d[j]);
+        ct += uint32_t(__popcll(__ballot(ok)));
+      }
+      mine = lane == m ? ct : mine;
+      total += ct;
+    }
+  }
+  if (lane < kWaveTiles && tile0 + lane < g.tiles_per_frame) fs.tcnt[tile0 + lane] = mine;
+  if (lane == 0) s_red[wave] = total;
+  __syncthreads();
+  if (tid == 0) fs.gsum[grp] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+template <int DT, int QK>
+__device__ __forceinline__ void chunk_scatter_block(const uint8_t *__restrict__ disp, float4 *__restrict__ out,
+                                                    uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
+                                                    uint8_t *state, const Geom &g, const QArg<QK> &Q, const ChunkArgs &c,
+                                                    uint32_t tile, uint32_t *s_red, uint32_t *s_cnt) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fl = fdiv(tile, g.div_tpf);
+  const uint32_t lt = tile - fl * g.tiles_per_frame;
+  const uint32_t f = c.scatter_f0 + fl;
+  const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
+  float4 *fout = out + uint64_t(f) * g.out_frame_stride;
+  uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
+  const ChunkFrameState fs(state, g, c, f);
+  const uint32_t base = lt * kChunkTile + tid;
+  float d[kChunkS];
+  uint32_t uu[kChunkS], vv[kChunkS];
+#pragma unroll
+  for (int k = 0; k < kChunkS; ++k) {
+    const uint32_t i = base + uint32_t(k) * uint32_t(kBlock);
+    const uint32_t v = fdiv(i, g.div_roi_w);
+    uu[k] = i - v * g.roi_w + g.border;
+    vv[k] = v + g.border;
+    const uint32_t off = vv[k] * g.row_stride + uu[k] * elem_bytes<DT>();
+    d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
+  }
+  // the tile's position in the frame's output: requested together with the disparities
+  const uint32_t grp = lt >> kChunkGroupShift, j = lt & (kChunkGroupTiles - 1u);
+  uint32_t before = 0;
+  for (uint32_t h = tid; h < grp; h += uint32_t(kBlock)) before += fs.gsum[h];
+  if (tid < j) before += fs.tcnt[(grp << kChunkGroupShift) + tid];
+  float X[kChunkS], Y[kChunkS], Z[kChunkS];
+  uint64_t mask[kChunkS];
+#pragma unroll
+  for (int k = 0; k < kChunkS; ++k) {
+    const uint32_t i = base + uint32_t(k) * uint32_t(kBlock);
+    reproject(Q, uu[k], vv[k], d[k], X[k], Y[k], Z[k]);
+    mask[k] = __ballot(i < g.roi_n && point_is_valid(X[k], Y[k], Z[k], d[k], g.min_disparity));
+  }
+  before = wave_sum(before);
+  if (lane == 0) {
+    s_red[wave] = before;
+#pragma unroll
+    for (int k = 0; k < kChunkS; ++k) s_cnt[k * 4 + int(wave)] = uint32_t(__popcll(mask[k]));  // cells in pixel order
+  }
+  __syncthreads();
+  const uint32_t prefix = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  uint32_t run = 0, cell[kChunkS] = {};
+#pragma unroll
+  for (int cidx = 0; cidx < kChunkS * 4; ++cidx) {
+#pragma unroll
+    for (int k = 0; k < kChunkS; ++k) cell[k] = uint32_t(cidx) == uint32_t(k) * 4u + wave ? run : cell[k];
+    run += s_cnt[cidx];
+  }
+#pragma unroll
+  for (int k = 0; k < kChunkS; ++k) {
+    const uint32_t pos = prefix + cell[k] + mbcnt64(mask[k]);
+    // pos < roi_n always holds; the guard keeps a count that is not this call's from becoming an out-of-bounds store
+    if (((mask[k] >> lane) & 1) && pos < g.roi_n) {
+      store_point<D2PC_CHUNK_STORE_NT != 0>(fout, pos, X[k], Y[k], Z[k]);
+      if (fidx) st<D2PC_CHUNK_INDEX_NT != 0>(fidx + pos, vv[k] * g.width + uu[k]);
+    }
+  }
+  if (counts && lt == g.tiles_per_frame - 1u && tid == 0) counts[f] = prefix + run;
+}
+
+template <int DT, int QK, bool VEC>
+__global__ __launch_bounds__(kBlock) void k_compact_chunk(const uint8_t *__restrict__ disp, float4 *__restrict__ out,
+                                                          uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
+                                                          uint8_t *state, const Geom g, const QArg<QK> Q, const ChunkArgs c) {
+  __shared__ uint32_t s_red[4], s_cnt[kChunkS * 4];
+  const uint32_t b = blockIdx.x;
+  const uint32_t q = fdiv(b, c.div_period), rem = b - q * c.period;
+  if (rem == 0 && q < c.count_blocks) {  // (block-uniform)
+    chunk_count_block<DT, QK, VEC>(disp, state, g, Q, c, q, s_red);
+    return;
+  }
+  uint32_t ahead = rem ? q + 1u : q;  // count blocks at positions below b
+  if (ahead > c.count_blocks) ahead = c.count_blocks;
+  chunk_scatter_block<DT, QK>(disp, out, out_index, counts, state, g, Q, c, b - ahead, s_red, s_cnt);
 }
 
 // --------------------------------------------------------------------------
@@ -2069,6 +2281,59 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
   return hipGetLastError();
 }
 
+// compact_algo 4: launch i scatters chunk i-1 and counts chunk i (launch 0 only counts, the last only scatters)
+template <int DT, int QK, bool VEC>
+static hipError_t launch_compact_chunked_t(const LaunchArgs &a) {
+  const Geom &g = a.geom;
+  if (g.pxt != uint32_t(kChunkS) || a.chunk_frames == 0 || a.chunk_first == 0 || g.tiles_per_frame == 0) return hipErrorInvalidValue;
+  ChunkArgs c{};
+  c.groups_per_frame = (g.tiles_per_frame + kChunkGroupTiles - 1u) / kChunkGroupTiles;
+  uint32_t gw = 0;
+  if (chunk_frame_state_stride(g.tiles_per_frame, &gw) != g.frame_state_stride) return hipErrorInvalidValue;
+  c.gsum_words = gw;
+  c.div_gpf = make_fastdiv(c.groups_per_frame);
+  uint32_t prev0 = 0, prevn = 0;  // the chunk counted by the previous launch
+  uint32_t next0 = 0;
+  for (;;) {
+    uint32_t nextn = next0 == 0 ? a.chunk_first : a.chunk_frames;
+    if (nextn > g.n_frames - next0) nextn = g.n_frames - next0;
+    c.scatter_f0 = prev0;
+    c.scatter_tiles = prevn * g.tiles_per_frame;
+    c.count_f0 = next0;
+    c.count_blocks = nextn * c.groups_per_frame;
+    const uint64_t grid = uint64_t(c.scatter_tiles) + c.count_blocks;
+    if (grid == 0) break;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    c.period = c.count_blocks ? uint32_t(grid / c.count_blocks) : 1u;
+    c.div_period = make_fastdiv(c.period);
+    hipLaunchKernelGGL((k_compact_chunk<DT, QK, VEC>), dim3(uint32_t(grid)), dim3(kBlock), 0, a.stream,
+                       static_cast<const uint8_t *>(a.disp), static_cast<float4 *>(a.out_points), a.out_index, a.counts,
+                       static_cast<uint8_t *>(a.state), g, make_qarg<QK>(a), c);
+    prev0 = next0;
+    prevn = nextn;
+    next0 += nextn;
+  }
+  return hipGetLastError();
+}
+template <int QK>
+static hipError_t launch_compact_chunked_q(const LaunchArgs &a) {
+  switch (a.dtype) {
+    case DT_F32: return a.vec_rows ? launch_compact_chunked_t<DT_F32, QK, true>(a) : launch_compact_chunked_t<DT_F32, QK, false>(a);
+    case DT_U8: return launch_compact_chunked_t<DT_U8, QK, false>(a);
+    case DT_U16: return launch_compact_chunked_t<DT_U16, QK, false>(a);
+  }
+  return hipErrorInvalidValue;
+}
+static hipError_t launch_compact_chunked(const LaunchArgs &a) {
+  switch (a.q_kind) {
+    case QK_STEREO: return launch_compact_chunked_q<QK_STEREO>(a);
+    case QK_STEREO_CV24: return launch_compact_chunked_q<QK_STEREO_CV24>(a);
+    case QK_STEREO_CV4: return launch_compact_chunked_q<QK_STEREO_CV4>(a);
+    case QK_GENERAL: return launch_compact_chunked_q<QK_GENERAL>(a);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <int DT, int QK, int S>
 static hipError_t launch_parity_small_t(const LaunchArgs &a) {
   hipLaunchKernelGGL((k_reproject_pack_small<DT, QK, S>), dim3(a.geom.total_tiles), dim3(kBlock), 0, a.stream,
@@ -2114,6 +2379,14 @@ bool tile_shape_supported(int pxt) { return pxt == 4 || pxt == 8 || pxt == 16; }
 uint32_t frame_state_stride(uint32_t tiles_per_frame) {
   const uint32_t groups = (tiles_per_frame + kGroupTiles - 1) / kGroupTiles;
   const uint64_t b = kFrameTicketBytes + uint64_t(groups) * kGroupAccStride + uint64_t(tiles_per_frame) * 16;
+  return uint32_t((b + 255) & ~uint64_t(255));
+}
+
+uint32_t chunk_frame_state_stride(uint32_t tiles_per_frame, uint32_t *gsum_words) {
+  const uint32_t groups = (tiles_per_frame + kChunkGroupTiles - 1u) / kChunkGroupTiles;
+  const uint32_t gw = (groups + 3u) & ~3u;
+  if (gsum_words) *gsum_words = gw;
+  const uint64_t b = 4ull * (uint64_t(gw) + tiles_per_frame);
   return uint32_t((b + 255) & ~uint64_t(255));
 }
 
@@ -2259,6 +2532,6 @@ hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const v
 }
 
 hipError_t launch_parity(const LaunchArgs &a) { return dispatch(a, false); }
-hipError_t launch_compact(const LaunchArgs &a) { return dispatch(a, true); }
+hipError_t launch_compact(const LaunchArgs &a) { return a.compact_algo == 4 ? launch_compact_chunked(a) : dispatch(a, true); }
 
 }  // namespace d2pc

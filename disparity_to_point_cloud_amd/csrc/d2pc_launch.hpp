@@ -20,7 +20,10 @@ struct LaunchArgs {
   void *stats = nullptr;          // device: CompactStats of the context (single pass)
   int dtype = DT_F32;
   int pxt = 4;                    // ROI pixels per thread (tile = 256*pxt)
-  int compact_algo = 1;           // 1 two-pass, 2 single-pass, 3 one launch of resident blocks (k_compact_resident)
+  int compact_algo = 1;           // 1 two-pass, 2 single-pass, 3 one launch of resident blocks (k_compact_resident),
+                                  // 4 chunked two-pass of one-shot blocks (k_compact_chunk; geom in 512-pixel tiles)
+  uint32_t chunk_frames = 0;      // algo 4: frames per chunk, and frames of the first chunk (only counted, nothing
+  uint32_t chunk_first = 0;       //         to overlap with: kept short)
   uint32_t epoch = 0;             // algo 3: this launch's epoch (kEpochBase <= epoch < kEpochEnd)
   bool parity_small = false;      // PARITY: one-shot blocks of 256 * pxt pixels (pxt 1, 2 or 4), k_reproject_pack_small
   bool vec_rows = false;          // fp32 rows fetchable 16 B per lane (alignment checked by the host)
@@ -90,6 +93,8 @@ hipError_t launch_rotate_cw(RotateArgs a, hipStream_t stream);
 
 bool tile_shape_supported(int pxt);
 uint32_t frame_state_stride(uint32_t tiles_per_frame);
+// algo 4: bytes of state per frame for frames of `tiles_per_frame` 512-pixel tiles, and the words its group totals take
+uint32_t chunk_frame_state_stride(uint32_t tiles_per_frame, uint32_t *gsum_words);
 size_t compact_state_bytes(const Geom &g);
 hipError_t launch_parity(const LaunchArgs &a);
 // tile-fused callback body (bit-sliced k x k median + PARITY reprojection of the tile from LDS;

@@ -15,9 +15,10 @@ def _batch(ctx, frames, want_index):
     from disparity_to_point_cloud_amd.torch_api import DeviceBatch
 
     n, (h, w) = len(frames), frames[0].shape
-    tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8}[frames[0].dtype]
+    tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16}[frames[0].dtype]
     b = DeviceBatch(ctx, n, h, w, dtype=tdt, want_index=want_index)
-    b.disp.copy_(torch.from_numpy(np.stack(frames)))
+    stack = np.stack(frames)
+    b.disp.copy_(torch.from_numpy(stack.view(np.int16)).view(tdt) if stack.dtype == np.uint16 else torch.from_numpy(stack))
     b.points.fill_(float("nan"))
     return b
 
@@ -37,7 +38,7 @@ def test_c4_4k_parity_batch(border):
         assert_points_close(pts, want, max_ulp=1, rel=1e-5, what=f"4K frame {f}")
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 4])
 def test_c4_4k_compact_batch(algo):
     q = d2pc.make_q()
     kinds = ["uniform", "holes", "blocky", "holes"]
@@ -55,9 +56,44 @@ def test_c4_4k_compact_batch(algo):
         assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"4K compact frame {f}")
 
 
+@pytest.mark.parametrize("chunk_mb,first", [(96, 0), (1, 0), (9, 1), (20, 3), (4096, 0), (17, 65535)])
+@pytest.mark.parametrize("dtype", ["f32", "f32_unaligned", "u8", "u16"])
+def test_chunked_two_pass_whatever_the_chunking(chunk_mb, first, dtype):
+    """compact_algo 4 (k_compact_chunk): launch i scatters chunk i-1 and counts chunk i.  The result may not depend on where
+    the batch is cut: one frame per chunk, ragged last chunks, a first chunk longer than the rest, one chunk for everything;
+    the 16-byte row loads of the count blocks (f32), their scalar path (an odd width; 8- and 16-bit input)."""
+    q = d2pc.make_q(cx=411.3, cy=140.2, nx=823, ny=291)
+    n, h, w = 11, 291, 823 if dtype == "f32_unaligned" else 824
+    rng = np.random.default_rng(w + chunk_mb)
+    if dtype.startswith("f32"):
+        frames = [synth_disparity(3, 70 + f, w, h, ["holes", "blocky", "uniform"][f % 3]) for f in range(n)]
+        scale = 1.0
+    else:
+        hi, dt = (256, np.uint8) if dtype == "u8" else (65536, np.uint16)
+        frames = [rng.integers(0, hi, size=(h, w)).astype(dt) for _ in range(n)]
+        for fr in frames:
+            fr[rng.random((h, w)) < 0.3] = 0
+        scale = 0.125 if dtype == "u8" else 1.0 / 64
+    frames[4][:] = 0          # a frame without a single valid point
+    with d2pc.Context(q=q, border=3, mode=d2pc.MODE_COMPACT, compact_algo=4) as ctx:
+        ctx.set_tuning("chunk_mb", chunk_mb)
+        ctx.set_tuning("chunk_first_frames", first)
+        b = _batch(ctx, frames, want_index=True)
+        for _ in range(2):
+            b.points.fill_(0)
+            b.launch(scale=scale)
+        res = b.results()
+        ctx.check_async_error()
+    for f, (pts, idx) in enumerate(res):
+        wp, wi = oracle.reproject_compact(frames[f], q, border=3, scale=scale)
+        assert len(pts) == len(wp), f"frame {f} count"
+        assert np.array_equal(idx, wi), f"frame {f}"
+        assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"frame {f}")
+
+
 def test_default_algorithm_on_a_large_batch():
-    """compact_algo = 0 picks the single pass for big launches (>= 4 frames,
-    >= ~25k tiles): 30 frames of 1920x1080 (27k tiles) with three validity
+    """compact_algo = 0 picks the big-batch form (the chunked two-pass; tuning big_batch_algo = 2: the single pass) for big
+    launches (>= 4 frames, >= ~25k tiles): 30 frames of 1920x1080 (27k tiles) with three validity
     patterns, relaunched, against the oracle."""
     q = d2pc.make_q()
     kinds = ["holes", "blocky", "uniform"]
@@ -115,7 +151,7 @@ def test_compact_is_idempotent_and_sorted_at_full_size(form, general):
     assert np.array_equal(roi, np.nonzero(keep)[0])
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3])  # count/scan/scatter nodes | memset + single-pass kernel nodes
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])  # count/scan/scatter nodes | memset + single-pass kernel nodes | chunk launches
 def test_launch_on_side_stream_and_graph_capture(algo):
     q = d2pc.make_q()
     frames = [synth_disparity(2, f, 640, 480, "holes") for f in range(6)]
@@ -151,7 +187,7 @@ def test_launch_on_side_stream_and_graph_capture(algo):
             assert_points_close(p1, wp, max_ulp=1)
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 def test_two_streams_in_flight_from_one_context_do_not_share_compaction_state(algo):
     """Double buffering: COMPACT launches of ONE context enqueued on two streams overlap on the device.
     Each launch must own its tickets / partial counts / granules (round 1 shared one buffer: points came
@@ -176,7 +212,7 @@ def test_two_streams_in_flight_from_one_context_do_not_share_compaction_state(al
             assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"two-stream frame {f}")
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 4])
 def test_graph_replay_survives_a_larger_eager_launch(algo):
     """A captured launch bakes its state pointer into the graph.  A later, LARGER eager launch needs more
     state: it must get a buffer of its own instead of freeing the graph's (round 1: use-after-free)."""

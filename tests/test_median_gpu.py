@@ -659,6 +659,44 @@ def test_tile_fused_compact_kernel_with_degenerate_scales_and_a_disparity_floor(
             assert np.array_equal(a, c), f"form {fused}"
 
 
+@pytest.mark.parametrize("n,h,w", [(500, 120, 400), (1000, 120, 160)])
+def test_tile_fused_compact_kernel_with_more_frames_than_resident_bands(n, h, w):
+    """Advisor, round 3: a frame needs a whole band of its tiles (tiles_x blocks) resident at once, and blocks go round-robin
+    over the launch's frames -- from ~resident / tiles_x frames on, no frame could finish band 0 and every wave span out its
+    wait budget.  400x120 (ROI 320x40: 2 tiles per band) x 500 frames is past that point on 256 CUs x 3 blocks; the host
+    now cuts such calls into sub-batches.  Both forms of the kernel against the two launches, bitwise; no timeouts."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    rng = np.random.default_rng(n)
+    imgs = rng.integers(0, 256, size=(n, h, w)).astype(np.uint8)
+    imgs[rng.random((n, h, w)) < 0.3] = 0
+    src = torch.from_numpy(imgs).cuda()
+    res = {}
+    with d2pc.Context(q=d2pc.make_q(), mode=d2pc.MODE_COMPACT) as ctx:
+        ctx.set_tuning("median_algo", 2)
+        ctx.set_tuning("spin_timeout_ms", 500)   # (a regression would otherwise spin 4 s per wave before failing)
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
+        ctx.compact_stats_reset()
+        for fused in (2, 1, 0):
+            ctx.set_tuning("callback_fused_compact", fused)
+            b.points.fill_(0)
+            b.index.fill_(-1)
+            b.counts.fill_(-7)
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125, b.points.data_ptr(),
+                                    b.index.data_ptr(), b.stride, b.counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ctx.check_async_error()
+            res[fused] = (b.points.cpu().numpy().view(np.uint32).copy(), b.index.cpu().numpy().copy(), b.counts.cpu().numpy().copy())
+            assert not (res[fused][2].view(np.uint32) == 0xFFFFFFFF).any(), f"form {fused}: a frame reports a timed-out hand-off"
+        assert ctx.compact_stats()["timeouts"] == 0
+    for fused in (1, 2):
+        for a, c in zip(res[fused], res[0]):
+            assert np.array_equal(a, c), f"form {fused} differs from the two launches"
+    for f in (0, n // 2, n - 1):
+        want, wi = oracle.reproject_compact(oracle.median_u8(imgs[f], 11), d2pc.make_q(), border=40, scale=0.125)
+        assert res[2][2].view(np.uint32)[f] == len(want)
+        assert np.array_equal(res[2][1].view(np.uint32).reshape(n, -1)[f][:len(wi)], wi)
+
+
 @pytest.mark.parametrize("form", [1, 2])
 def test_tile_fused_compact_kernel_is_capturable_and_runs_on_two_streams(form):
     """Captured without a warm-up call after d2pc_reserve_mono (its hand-off state is the capture's own), replayed

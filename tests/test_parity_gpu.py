@@ -214,7 +214,7 @@ def test_tile_shapes_agree_bitwise(q_default, pxt):
 
 
 # --------------------------------------------------------------- compact mode
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 @pytest.mark.parametrize("kind", ["holes", "blocky", "uniform"])
 def test_compact_vs_oracle_small(q_default, kind, algo):
     disp = synth_disparity(3, 0, 640, 360, kind)
@@ -228,7 +228,7 @@ def test_compact_vs_oracle_small(q_default, kind, algo):
     assert m.is_dense == 1 and m.width == len(gp)
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 def test_c3_1080p_30pct_invalid(q_default, algo):
     """BASELINE.json configs[2]: 1920x1080 fp32, ~30 % invalid, compaction on."""
     for kind in ("holes", "blocky"):
@@ -242,7 +242,7 @@ def test_c3_1080p_30pct_invalid(q_default, algo):
         assert 0.6 < len(gp) / 1840000 < 0.8
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 @pytest.mark.parametrize("pxt", [4, 8, 16])
 def test_compact_edge_patterns(q_default, algo, pxt):
     rng = np.random.default_rng(99)
@@ -264,7 +264,7 @@ def test_compact_edge_patterns(q_default, algo, pxt):
             assert_points_close(gp, wp, max_ulp=MAX_ULP, what=name)
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 def test_compact_tiny_w_takes_exact_slow_path(algo):
     """W so small that coordinates overflow float32 for part of the frame:
     the count pass's cheap predicate must fall back to the real arithmetic
@@ -320,15 +320,20 @@ def _same_bits(got, want, what=""):
     assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan]), what
 
 
+@pytest.mark.parametrize("q33", [None, 0.37, -1.0 / 3.0])
 @pytest.mark.parametrize("w,h,border,cx", [(752, 480, 40, 376.0), (3840, 2160, 40, 1919.5), (1025, 67, 0, 511.37),
                                            (4099, 5, 1, 2050.123456789), (333, 200, 7, 0.1), (640, 360, 0, -3.75),
                                            (65, 33, 0, 1e-9)])
-def test_reproject_form_selects_one_opencv_generation_bit_for_bit(w, h, border, cx):
+def test_reproject_form_selects_one_opencv_generation_bit_for_bit(w, h, border, cx, q33):
     """Tuning reproject_form: 24 = OpenCV 2.4's loop (running column sum qx += q00, replayed by the host into a table of
     its roundings), 4 = OpenCV 3/4's Matx product with float numerators.  Each against the oracle's form of the same
     name at 0 ulp on cv::stereoRectify's Q -- the calibrated path --, PARITY and COMPACT, with holes, NaN and inf in
-    the input.  (The default for that Q is the specialised kernel: <= 1 ulp from both, ~25 % less arithmetic.)"""
+    the input.  (The default for that Q is the specialised kernel: <= 1 ulp from both, ~25 % less arithmetic.)
+    q33 != 0 is stereoRectify WITHOUT CALIB_ZERO_DISPARITY (different principal points): W = q33 + RN(q32 * d) then
+    rounds twice in both generations, where the default kind's fused multiply-add rounds once."""
     q = d2pc.make_q(cx=cx, cy=h / 2 - 0.3, nx=w, ny=h)
+    if q33 is not None:
+        q[15] = q33
     disp = synth_disparity(3, w + h, w, h, "holes")
     disp[h // 2, w // 2 : w // 2 + 6] = [np.nan, np.inf, -np.inf, -1.0, 3.4028235e38, 1e-45][: min(6, w - w // 2)]
     for form, oform in ((24, oracle.FORM_CV24), (4, oracle.FORM_CV4)):
@@ -343,7 +348,7 @@ def test_reproject_form_selects_one_opencv_generation_bit_for_bit(w, h, border, 
                 _same_bits(ctx.process(disp), want, f"form {form} general={general} {w}x{h}")
                 ctx.set_tuning("pxt_parity", 8)   # the tile-walking kernel too
                 _same_bits(ctx.process(disp), want, f"form {form} general={general} {w}x{h} (tiles)")
-            for algo in (1, 2, 3):
+            for algo in (1, 2, 3, 4):
                 with ctx_for(q, border=border, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
                     ctx.set_reproject_form(form)
                     ctx.set_tuning("force_general_q", general)

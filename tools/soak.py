@@ -29,7 +29,7 @@ for c in range(cases):
     border = int(rng.choice([0, 0, 1, 3, 8, 40, 40, 57]))
     dt = rng.choice(["f32", "u8", "u16"])
     mode = rng.choice(["parity", "compact"])
-    algo = int(rng.choice([0, 1, 2]))
+    algo = int(rng.choice([0, 1, 2, 3, 4]))
     idx = bool(rng.random() < 0.5)
     holes = float(rng.choice([0.0, 0.05, 0.3, 0.9, 1.0]))
     stereo = bool(rng.random() < 0.7)
@@ -39,6 +39,8 @@ for c in range(cases):
         q[12:14] = rng.uniform(0, 1e-3, 2); q[14] = rng.uniform(0.01, 1); q[15] = rng.uniform(0.1, 2)
     elif rng.random() < 0.3:
         q = d2pc.make_q(fx=500 + 300 * rng.random(), fy=600 + 200 * rng.random(), cx=w / 2, cy=h / 2, baseline=0.05 + rng.random(), nx=w + 1, ny=h + 1)
+    if stereo and rng.random() < 0.3:
+        q[15] = rng.uniform(-1, 1)   # stereoRectify without CALIB_ZERO_DISPARITY: W = q33 + RN(q32 * d) rounds twice in both OpenCV forms
     if dt == "f32":
         frames = rng.uniform(0.5, 128, size=(n, h, w)).astype(np.float32); scale = 1.0; tdt = torch.float32
     elif dt == "u8":
@@ -52,6 +54,8 @@ for c in range(cases):
     with d2pc.Context(q=q, border=border, mode=m, compact_algo=algo) as ctx:
         ctx.set_reproject_form(rform)
         ctx.set_tuning("force_general_q", int(fgen))
+        if algo == 4:
+            ctx.set_tuning("chunk_mb", int(rng.choice([1, 2, 96])))
         b = DeviceBatch(ctx, n, h, w, dtype=tdt, want_index=idx)
         b.disp.copy_(torch.from_numpy(frames.view(np.int16) if dt == "u16" else frames).view(tdt))
         b.launch(scale=scale)
