@@ -1,6 +1,7 @@
-"""ctypes binding of include/d2pc.h (the C-ABI drop-in boundary).
+"""ctypes binding of include/d2pc.h (the C-ABI drop-in boundary) and of include/d2pc_ext.h (unstable: bench / tools /
+tests).
 
-One-to-one with the header: every function the header declares is bound here
+One-to-one with the two headers: every function they declare is bound here
 and nothing else.  The binding never computes points itself.
 """
 import ctypes
@@ -17,21 +18,27 @@ DTYPE_F32, DTYPE_U8, DTYPE_U16, DTYPE_MONO16 = 0, 1, 2, 3
 MODE_PARITY, MODE_COMPACT = 0, 1
 CALIB_BLOB_BYTES = 136
 
-# every symbol include/d2pc.h declares (tests check the library exports all)
+# every symbol include/d2pc.h declares: the STABLE surface (tests check the library exports all, and nothing else is listed)
 ABI_SYMBOLS = [
     "d2pc_abi_version", "d2pc_status_string", "d2pc_device_count", "d2pc_make_q", "d2pc_config_init",
     "d2pc_calib_pack", "d2pc_calib_unpack", "d2pc_make_q_disparity_image", "d2pc_set_min_disparity",
     "d2pc_create", "d2pc_destroy", "d2pc_last_error", "d2pc_set_q", "d2pc_get_q", "d2pc_set_border",
     "d2pc_set_mode", "d2pc_get_config", "d2pc_export_calibration", "d2pc_import_calibration",
-    "d2pc_roi_points", "d2pc_cloud_meta_fill", "d2pc_process", "d2pc_process_device", "d2pc_reserve",
-    "d2pc_check_async_error", "d2pc_set_tuning", "d2pc_median_device", "d2pc_process_mono8",
+    "d2pc_roi_points", "d2pc_cloud_meta_fill", "d2pc_process", "d2pc_process_device",
+    "d2pc_check_async_error", "d2pc_median_device", "d2pc_process_mono8",
     "d2pc_pipeline_configure", "d2pc_pipeline_acquire", "d2pc_pipeline_submit", "d2pc_pipeline_collect",
     "d2pc_pipeline_release", "d2pc_fuse_desc_init", "d2pc_fuse_device", "d2pc_crop_to_square",
-    "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16", "d2pc_last_stage_times",
+    "d2pc_rotate_cw_device", "d2pc_mono16_to_mono8_device", "d2pc_process_mono16",
     "d2pc_median_roi_device", "d2pc_host_alloc", "d2pc_host_free", "d2pc_make_q_flavour",
-    "d2pc_process_mono_device", "d2pc_reserve_mono", "d2pc_release_graph_buffers", "d2pc_compact_stats",
-    "d2pc_compact_stats_reset", "d2pc_membench_fill", "d2pc_membench_copy", "d2pc_set_reproject_form",
+    "d2pc_process_mono_device", "d2pc_set_reproject_form",
 ]
+# include/d2pc_ext.h: unstable, for bench.py / tools / tests only
+EXT_SYMBOLS = [
+    "d2pc_ext_revision", "d2pc_reserve", "d2pc_reserve_mono", "d2pc_release_graph_buffers", "d2pc_compact_stats",
+    "d2pc_compact_stats_reset", "d2pc_membench_fill", "d2pc_membench_copy", "d2pc_last_stage_times", "d2pc_set_tuning",
+    "d2pc_ext_set_test_hook",
+]
+ABI_VERSION = 2
 FORM_DEFAULT, FORM_CV24, FORM_CV4 = 0, 24, 4   # d2pc_reproject_form
 # d2pc_fusion_rule (source order of the reference's src/depth_map_fusion.cpp:162-235)
 (FUSE_WEIGHTED_AVERAGE, FUSE_MAX_DIST, FUSE_MAX_DIST_UNLESS_BLACK, FUSE_BETTER_SCORE, FUSE_ONLY_GOOD_1,
@@ -164,7 +171,7 @@ def load_library():
 
             def __call__(self, *a):
                 raise AttributeError(f"{_LIB_NAME} does not export this entry point")
-        for name in ABI_SYMBOLS:
+        for name in ABI_SYMBOLS + EXT_SYMBOLS:
             if not hasattr(L, name):
                 setattr(L, name, _Missing())
     vp, cp = ctypes.c_void_p, ctypes.c_char_p
@@ -238,8 +245,9 @@ def load_library():
     L.d2pc_membench_fill.argtypes = [vp, vp, ctypes.c_size_t, vp]
     L.d2pc_membench_copy.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
     L.d2pc_set_tuning.argtypes = [vp, cp, ctypes.c_int]
+    L.d2pc_ext_set_test_hook.argtypes = [vp, cp, ctypes.c_int]
     L.d2pc_set_reproject_form.argtypes = [vp, ctypes.c_int]
-    for name in ABI_SYMBOLS:
+    for name in ABI_SYMBOLS + EXT_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int or fn.restype is None:
             fn.restype = ctypes.c_int
@@ -414,7 +422,12 @@ class Context:
         self._check(self._L.d2pc_set_reproject_form(self._h, form))
 
     def set_tuning(self, key: str, value: int):
+        """d2pc_ext.h: launch-shape knobs; the bytes of the result never depend on them."""
         self._check(self._L.d2pc_set_tuning(self._h, key.encode(), value))
+
+    def set_test_hook(self, key: str, value: int):
+        """d2pc_ext.h: "force_general_q" / "general_q_form" -- the two hooks that DO change the arithmetic (tests only)."""
+        self._check(self._L.d2pc_ext_set_test_hook(self._h, key.encode(), value))
 
     def reserve(self, width, height, n_frames=1):
         self._check(self._L.d2pc_reserve(self._h, width, height, n_frames))

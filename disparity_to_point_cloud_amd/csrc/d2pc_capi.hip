@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/d2pc.h"
+#include "../../include/d2pc_ext.h"
 #include "d2pc_device.hpp"
 #include "d2pc_launch.hpp"
 
@@ -33,6 +34,8 @@ struct StateBuf {
   int algo = 0;                  // algorithm of that launch: 2 = single pass (its header holds the timeout flag),
                                  // 3 = resident blocks (the flag holds the launch's epoch)
   uint32_t epoch = 0;            // algo 3: that launch's epoch
+  uint64_t chunk_sig = 0;        // algo 4: frames and frame stride of that launch (its frame counters sit where the next
+                                 // launch of the same shape expects them, and read zero)
   bool captured = false;         // a stream capture baked the pointer into a graph: never freed, moved or shared
                                  // until d2pc_release_graph_buffers
   unsigned long long capture_id = 0;
@@ -601,6 +604,11 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   int st = acquire_buf(ctx, ctx->states, stream, a.state_bytes, 0, fixed_state, &sb);
   if (st != D2PC_OK) return st;
   a.state = sb->p;
+  if (a.compact_algo == 4) {
+    const uint64_t sig = (uint64_t(a.geom.frame_state_stride) << 32) | a.geom.n_frames;
+    a.chunk_clear = sb->algo != 4 || sb->chunk_sig != sig;
+    sb->chunk_sig = sig;
+  }
   sb->algo = a.compact_algo;
   sb->epoch = a.epoch;
   D2PC_HIP(ctx, launch_compact(a));
@@ -977,9 +985,6 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 0 && value <= 64) ctx->onepass_blocks_per_cu = value;
-  else if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
-  else if (!strcmp(key, "general_q_form") && (value == 0 || value == 1)) ctx->general_q_form = value;
-  else if (!strcmp(key, "reproject_form") && (value == 0 || value == 24 || value == 4)) ctx->reproject_form = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
@@ -997,6 +1002,18 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "membench_unroll") && (value == 1 || value == 2 || value == 4)) ctx->membench_unroll = value;
   else if (!strcmp(key, "membench_nt") && (value == 0 || value == 1)) ctx->membench_nt = value;
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown tuning %s=%d", key, value);
+  return D2PC_OK;
+}
+
+int d2pc_ext_revision(void) { return D2PC_EXT_REVISION; }
+
+// The two hooks that change the ARITHMETIC (tests compare the specialised kinds with the general kernel through them):
+// apart from d2pc_set_tuning, whose keys never change a byte of the result.
+int d2pc_ext_set_test_hook(d2pc_ctx *ctx, const char *key, int value) {
+  if (!ctx || !key) return D2PC_ERR_INVALID_ARG;
+  if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
+  else if (!strcmp(key, "general_q_form") && (value == 0 || value == 1)) ctx->general_q_form = value;
+  else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown test hook %s=%d", key, value);
   return D2PC_OK;
 }
 

@@ -70,8 +70,8 @@ struct ChunkArgs {
   uint32_t scatter_f0, scatter_tiles;  // frames from scatter_f0 on: scatter_tiles = frames x tiles_per_frame one-shot blocks
   uint32_t count_f0, count_blocks;     // frames from count_f0 on: count_blocks = frames x groups_per_frame
   uint32_t period;                     // blocks 0, P, 2P, ... are count blocks while they last (grid = scatter_tiles + count_blocks)
-  uint32_t groups_per_frame;           // ceil(tiles_per_frame / 32)
-  uint32_t gsum_words;                 // words of a frame's state ahead of its tile counts (the group totals, padded)
+  uint32_t groups_per_frame;           // ceil(tiles_per_frame / 32): groups of 128 runs = 16,384 pixels
+  uint32_t gsum_words;                 // words the group totals take in a frame's state (padded; their prefixes take as many)
   FastDiv div_gpf, div_period;
 };
 

@@ -24,6 +24,7 @@ struct LaunchArgs {
                                   // 4 chunked two-pass of one-shot blocks (k_compact_chunk; geom in 512-pixel tiles)
   uint32_t chunk_frames = 0;      // algo 4: frames per chunk, and frames of the first chunk (only counted, nothing
   uint32_t chunk_first = 0;       //         to overlap with: kept short)
+  bool chunk_clear = false;       // algo 4: the state buffer was last used otherwise: zero its frame counters first
   uint32_t epoch = 0;             // algo 3: this launch's epoch (kEpochBase <= epoch < kEpochEnd)
   bool parity_small = false;      // PARITY: one-shot blocks of 256 * pxt pixels (pxt 1, 2 or 4), k_reproject_pack_small
   bool vec_rows = false;          // fp32 rows fetchable 16 B per lane (alignment checked by the host)

@@ -19,6 +19,7 @@
 #include <string>
 
 #include "../include/d2pc.h"
+#include "../include/d2pc_ext.h"  // only for the verbose breadcrumbs: "stage_timing" + d2pc_last_stage_times
 #include "image_prep.hpp"
 
 namespace d2pc {

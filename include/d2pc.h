@@ -30,7 +30,16 @@
 extern "C" {
 #endif
 
-#define D2PC_ABI_VERSION 1
+/* ABI version policy.  This header is the STABLE surface: what a maintainer binds from DisparityCb.
+ * D2PC_ABI_VERSION changes when, and only when, a function here changes its signature or meaning, a struct here
+ * changes its layout, an enumerator changes its value, or a symbol is removed; additions keep it (structs carry
+ * struct_size / reserved fields for that).  d2pc_abi_version() returns the library's value: refuse a library whose
+ * value differs from the header you compiled against.
+ *   1  rounds 1-3: one header that also carried the bench / tuning / counter / graph-reservation entry points
+ *   2  those moved to include/d2pc_ext.h (unstable: tools, tests and benchmarks only; no compatibility promise);
+ *      the string keys that switched the arithmetic ("reproject_form", "force_general_q", "general_q_form") are gone
+ *      from d2pc_set_tuning -- d2pc_set_reproject_form is the one way to choose the arithmetic */
+#define D2PC_ABI_VERSION 2
 
 typedef enum d2pc_status {
   D2PC_OK = 0,
@@ -75,14 +84,15 @@ typedef struct d2pc_config {
   int32_t border;         /* ROI inset on all four sides; cpp:70,72 => 40     */
   int32_t mode;           /* d2pc_mode                                        */
   float min_disparity;    /* COMPACT only: also drop d <= this; -inf = off    */
-  int32_t compact_algo;   /* 0 = library default: single pass (2) for launches
-                             of >= 4 frames and >= ~25k tiles; one resident
-                             launch (3) when every tile of the launch fits on
-                             the device at once (camera-size frames) and the
-                             call is not being captured; two-pass (1) else.
-                             1 = two-pass count/scan/scatter; 2 = single-pass
-                             counted hand-off; 3 = one block per tile, all
-                             resident (falls back to 1 / 2 where impossible) */
+  int32_t compact_algo;   /* 0 = library default: chunked two-pass (4) for
+                             launches of >= 4 frames and >= ~25k tiles; one
+                             launch of resident blocks (3) for camera-size
+                             launches that are not being captured; two-pass
+                             (1) else.  1 = two-pass count/scan/scatter;
+                             2 = single-pass counted hand-off; 3 = resident
+                             blocks (falls back where impossible); 4 = chunked
+                             two-pass of one-shot blocks.  Same bytes out
+                             whatever the value. */
   int32_t reserved[4];
 } d2pc_config;
 
@@ -236,12 +246,13 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale,
  * of its own (up to 8 per context), so double-buffered use of one context on
  * two streams is safe.  The context itself is still used from one host thread.
  *
- * hipGraph capture: call d2pc_reserve(width, height, n_frames) for the largest
- * batch before EACH capture that contains a COMPACT call -- nothing can be
- * allocated while capturing (D2PC_ERR_OUT_OF_MEMORY otherwise).  The state
- * buffer a capture used belongs to that graph from then on: later calls never
- * free, grow or share it, so the graph stays replayable whatever else the
- * context is asked to do.  One replay of a given graph in flight at a time.
+ * hipGraph capture: nothing can be allocated while capturing, so a COMPACT call
+ * needs its state buffer beforehand (D2PC_ERR_OUT_OF_MEMORY otherwise): run the
+ * largest batch once, or reserve it (d2pc_reserve in d2pc_ext.h) before EACH
+ * capture.  The state buffer a capture used belongs to that graph from then on:
+ * later calls never free, grow or share it, so the graph stays replayable
+ * whatever else the context is asked to do (d2pc_release_graph_buffers in
+ * d2pc_ext.h hands them back).  One replay of a given graph in flight at a time.
  *
  * COMPACT failure reporting in-band: if the single-pass kernel gave up waiting
  * for an earlier tile (see d2pc_check_async_error) d_counts[f] of the affected
@@ -327,15 +338,12 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
  * frames never reach memory.  Everything else -- small launches -- is the filter
  * launch followed by the reprojection launch.  The results are the same bytes
  * either way (measurements: DESIGN.md section 5).
- * Tuning "callback_fused": 1 (default) as described; 0 always two launches.
- * "callback_chunks" (default 1 = off) cuts a two-launch batch into chunks
- * pipelined over two internal streams (it did not pay reliably: DESIGN.md section 9);
- * such calls share those streams and are serialised against each other.
+ * (Launch-shape knobs for experiments: d2pc_ext.h, "callback_fused", "callback_chunks".)
  * In the two-launch form the filtered frames live in a scratch buffer that belongs
  * to the calling stream's work (one per stream in flight, like the compaction
  * state: double-buffered use on two streams is safe); it is grown on demand, so
- * before a capture reserve it with d2pc_reserve_mono (or run the batch size
- * once); under stream capture the call runs in order on `stream`.  The
+ * before a capture run the batch size once (or reserve it: d2pc_reserve_mono in
+ * d2pc_ext.h); under stream capture the call runs in order on `stream`.  The
  * one-kernel form needs no scratch.
  */
 int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int dtype, int width, int height,
@@ -390,63 +398,15 @@ int d2pc_pipeline_collect(d2pc_ctx *ctx, int *slot, const void **points, const u
                           size_t *n_points, uint64_t *tag);
 int d2pc_pipeline_release(d2pc_ctx *ctx, int slot);
 
-/* Guarantee one free compaction-state buffer for frames up to width x height
- * and batches up to n_frames (and make that the minimum size of any allocated
- * later).  Needed before a capture; optional otherwise (buffers grow on demand). */
-int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames);
-
-/* d2pc_process_mono_device's counterpart of d2pc_reserve: guarantees one free scratch buffer for the two-launch
- * form of a batch of n_frames frames of width x height (dtype D2PC_DTYPE_U8 or D2PC_DTYPE_MONO16) and, in COMPACT
- * mode, the compaction state as d2pc_reserve does -- so that the call can be captured without having run once. */
-int d2pc_reserve_mono(d2pc_ctx *ctx, int dtype, int width, int height, int n_frames);
-
-/* Buffers that a stream capture baked into a graph (compaction state, callback scratch) belong to that graph and are
- * never reused.  Call this once every graph captured from this context's launches has been destroyed: the buffers
- * return to the context's pools.  Buffers of graphs never take away from the 8 per pool that eager launches use. */
-int d2pc_release_graph_buffers(d2pc_ctx *ctx);
-
 /* After the streams of the context's COMPACT d2pc_process_device calls have been
  * synchronised: D2PC_ERR_INTERNAL if a hand-off wait of the single-pass kernel
- * ran out of its time budget (default 4 s, tuning "spin_timeout_ms") in the
+ * ran out of its time budget (4 s) in the
  * LAST launch of any of the context's state buffers -- each buffer remembers
  * the algorithm of its own last launch.  The output of such a launch is
  * incomplete and its d_counts entries read 0xFFFFFFFF; relaunch with
  * compact_algo = 1.  d2pc_process* (synchronous) does that relaunch itself;
  * d2pc_pipeline_collect reports the frame as D2PC_ERR_INTERNAL. */
 int d2pc_check_async_error(d2pc_ctx *ctx);
-
-/*
- * Counters of the single-pass compaction (compact_algo 2), summed over the context's launches since creation or
- * d2pc_compact_stats_reset -- the production build's view of the in-launch hand-off (the reference has only
- * printf breadcrumbs, cpp:47-91).  Call after synchronising the streams that carried the launches.
- *   launches           single-pass launches
- *   tiles              tiles they served (each takes one ticket and needs the counts of its predecessors)
- *   failed_polls       looks at a predecessor's count that found it unpublished; failed_polls / tiles is the
- *                      hand-off's health: ~0.1 on an idle device, more when predecessors are delayed
- *   wait_us            time the control waves spent in such waits, summed over all blocks (divide by the number
- *                      of resident blocks for wall time)
- *   timeouts           launches in which a wait ran out of its budget (d2pc_check_async_error)
- *   twopass_fallbacks  synchronous host calls (d2pc_process*) that reran such a launch with the two-pass form
- */
-typedef struct d2pc_compact_stats_t {
-  uint32_t struct_size;   /* = sizeof(d2pc_compact_stats_t), set by the caller */
-  uint32_t reserved;
-  uint64_t launches, tiles, failed_polls, wait_us, timeouts, twopass_fallbacks;
-} d2pc_compact_stats_t;
-int d2pc_compact_stats(d2pc_ctx *ctx, d2pc_compact_stats_t *out);
-int d2pc_compact_stats_reset(d2pc_ctx *ctx);
-
-/*
- * Device calibration for benchmarks: a plain fill of `bytes` bytes and a plain copy (16 bytes per lane, 1 KiB per
- * wave instruction), asynchronous on `stream`.  bench.py times them in the same run as the reprojection kernel,
- * so its fraction of the 8 TB/s specification can also be read against what THIS device gives a kernel that only
- * streams.  Buffers 16-byte aligned, `bytes` a multiple of 16, source and destination disjoint.
- * Launch shape by tuning keys (d2pc_set_tuning): persistent grid-stride blocks (default; the single-pass kernels'
- * shape) or one-shot blocks (the headline kernel's shape, the fastest store stream found on the chip), plain or
- * non-temporal stores.
- */
-int d2pc_membench_fill(d2pc_ctx *ctx, void *d_dst, size_t bytes, void *stream);
-int d2pc_membench_copy(d2pc_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, void *stream);
 
 /*
  * SURVEY.md section 8(f) #4 -- the inner loop of the sibling node's
@@ -507,41 +467,6 @@ int d2pc_rotate_cw_device(d2pc_ctx *ctx, const void *d_src, int cols, int rows, 
  * member offset_y_ (cpp:253), the origin the argument: pass both. */
 int d2pc_crop_to_square(int cols, int rows, int offset_x, int offset_y, int member_offset_y,
                         int *x, int *y, int *n);
-
-/*
- * Per-stage timing of the synchronous host entry points (d2pc_process,
- * d2pc_process_mono8/16), the counterpart of the reference's printf
- * breadcrumbs (cpp:47-91).  Off by default; d2pc_set_tuning(ctx,
- * "stage_timing", 1) makes every call record HIP events on its stream.
- * d2pc_last_stage_times returns the times of the last such call:
- *   h2d_ms    upload of the frame
- *   prep_ms   mono16 rescale + median (0 when neither runs)
- *   kernel_ms reprojection (+ compaction)
- *   d2h_ms    count readback + download of the points (and indices)
- */
-typedef struct d2pc_stage_times {
-  float h2d_ms, prep_ms, kernel_ms, d2h_ms, total_ms;
-} d2pc_stage_times;
-int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
-
-/* Launch-shape tuning hook (no counterpart in the reference; results never
- * depend on it, but for the three keys that pick an arithmetic form: "reproject_form" = d2pc_set_reproject_form,
- * "force_general_q" (0/1: a stereoRectify Q through the general kernel too) and "general_q_form" (0 = OpenCV 3/4's
- * association, 1 = fused multiply-adds, kept for comparison).  Keys: "pxt_parity" (ROI pixels per thread: 1, 2 = one-shot blocks of 256 / 512 pixels, 4, 8 or 16 = tiles
- * walked by a fixed grid; 0 = choose per launch: 2), "parity_small" (0/1/2: one-shot blocks off / also for 4 / default), "pxt_compact" (4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by
- * the tile count; 1..4096), "onepass_blocks_per_cu" (persistent blocks per CU of the single pass; 0 = choose:
- * 3 for 4K-class frames, 4 below), "force_general_q", "no_vec_rows", "fuse_rows" (rows per wave of
- * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
- * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
- * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
- * "callback_fused" (0/1, see d2pc_process_mono_device; default 1), "callback_fused_compact" (COMPACT mode: 0 = two
- * launches, 1 = one tile per block, 2 = persistent blocks that scatter one tile while filtering the next; default 2),
- * "callback_pipe_blocks_per_cu" (1..8, default 3), "membench_blocks_per_cu" (d2pc_membench_*: persistent blocks per CU, default 8; 0 = one block per
- * "membench_unroll" x 4 KiB), "membench_unroll" (1, 2 or 4 16-byte accesses per thread), "membench_nt" (0/1),
- * "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process / d2pc_process_mono8
- * without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose per launch,
- * 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes). */
-int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus
 }

@@ -14,23 +14,53 @@ from disparity_to_point_cloud_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "d2pc.h")).read()
+def _header_functions(name="d2pc.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(d2pc_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
+    """Both headers against the library and the binding: include/d2pc.h is the stable drop-in surface, include/d2pc_ext.h
+    the unstable one for bench / tools / tests."""
     lib = d2pc.load_library()
-    declared = _header_functions()
-    assert len(declared) >= 20
-    for name in declared:
+    stable, ext = _header_functions("d2pc.h"), _header_functions("d2pc_ext.h")
+    assert len(stable) >= 20 and len(ext) >= 8 and not set(stable) & set(ext)
+    for name in stable + ext:
         assert hasattr(lib, name), f"libd2pc.so does not export {name}"
-    assert sorted(capi.ABI_SYMBOLS) == declared, "python binding and header disagree"
+    assert sorted(capi.ABI_SYMBOLS) == stable, "python binding and d2pc.h disagree"
+    assert sorted(capi.EXT_SYMBOLS) == ext, "python binding and d2pc_ext.h disagree"
+
+
+def test_library_exports_nothing_undeclared():
+    """Every d2pc_* symbol the shared object exports is declared in one of the two headers (no hidden surface)."""
+    import subprocess
+    so = os.path.join(ROOT, "disparity_to_point_cloud_amd", "libd2pc.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("d2pc_")
+                       and ln.split()[-2] in ("T", "W")})
+    assert exported == sorted(_header_functions("d2pc.h") + _header_functions("d2pc_ext.h"))
+
+
+def test_stable_header_holds_no_tool_surface():
+    """What round 3's verdict asked to move out: no tuning strings, bench kernels, counters or graph plumbing in d2pc.h;
+    the adaptor and the host mirror include d2pc_ext.h only where they print stage times."""
+    stable = _header_functions("d2pc.h")
+    for name in ("d2pc_set_tuning", "d2pc_membench_fill", "d2pc_membench_copy", "d2pc_compact_stats", "d2pc_reserve",
+                 "d2pc_reserve_mono", "d2pc_release_graph_buffers", "d2pc_last_stage_times", "d2pc_ext_set_test_hook"):
+        assert name not in stable
+    assert "d2pc_set_reproject_form" in stable
+    lib = d2pc.load_library()
+    assert lib.d2pc_ext_revision() >= 4
+    for rel in ("ros/disparity_to_point_cloud_node.cpp", "host/multi_gpu.hpp", "host/image_prep.hpp", "host/pinned_allocator.hpp",
+                "host/replay_main.cpp"):
+        assert "d2pc_ext.h" not in open(os.path.join(ROOT, rel)).read(), rel
+    ext_calls = set(re.findall(r"\b(d2pc_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "host", "disparity_to_point_cloud_amd.hpp")).read()))
+    assert ext_calls & set(capi.EXT_SYMBOLS) <= {"d2pc_set_tuning", "d2pc_last_stage_times"}
 
 
 def test_abi_version_and_status_strings():
-    assert d2pc.abi_version() == 1
+    assert d2pc.abi_version() == capi.ABI_VERSION == 2
     assert d2pc.status_string(0) == "ok"
     for s in range(1, 10):
         assert d2pc.status_string(s) not in ("", "ok", "unknown status")
@@ -168,9 +198,9 @@ def test_public_header_is_plain_c99_and_cxx11(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "hdr.c"
-    src.write_text('#include "d2pc.h"\nint main(void) { d2pc_config c; d2pc_fuse_desc f; d2pc_frame_desc d; '
-                   'd2pc_stage_times t; d2pc_cloud_meta m; (void)c; (void)f; (void)d; (void)t; (void)m; '
-                   'return D2PC_ABI_VERSION == 1 ? 0 : 1; }\n')
+    src.write_text('#include "d2pc.h"\n#include "d2pc_ext.h"\nint main(void) { d2pc_config c; d2pc_fuse_desc f; d2pc_frame_desc d; '
+                   'd2pc_stage_times t; d2pc_cloud_meta m; d2pc_compact_stats_t s; (void)c; (void)f; (void)d; (void)t; (void)m; (void)s; '
+                   'return D2PC_ABI_VERSION == 2 && D2PC_EXT_REVISION >= 4 ? 0 : 1; }\n')
     inc = os.path.join(root, "include")
     for cmd in (["gcc", "-std=c99"], ["g++", "-std=c++11", "-x", "c++"]):
         p = subprocess.run(cmd + ["-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o",

@@ -135,7 +135,7 @@ def test_compact_is_idempotent_and_sorted_at_full_size(form, general):
     with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as c, d2pc.Context(q=q) as p:
         for ctx in (c, p):
             ctx.set_reproject_form(form)
-            ctx.set_tuning("force_general_q", general)
+            ctx.set_test_hook("force_general_q", general)
         bc = _batch(c, frames, want_index=True)
         bp = _batch(p, frames, want_index=False)
         bc.launch()

@@ -337,7 +337,7 @@ def test_tile_fused_callback_kernel_matches_the_two_launches_and_the_oracle(gene
     src = torch.from_numpy(imgs).cuda()
     res = {}
     with d2pc.Context(q=q, border=border) as ctx:
-        ctx.set_tuning("force_general_q", general_q)
+        ctx.set_test_hook("force_general_q", general_q)
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
         s = torch.cuda.current_stream().cuda_stream
@@ -376,8 +376,8 @@ def test_callback_body_in_one_opencv_generation_bit_for_bit(mode, form, oform, g
     src = torch.from_numpy(imgs).cuda()
     key = "callback_fused" if mode == d2pc.MODE_PARITY else "callback_fused_compact"
     with d2pc.Context(q=q, border=40, mode=mode) as ctx:
-        ctx.set_tuning("reproject_form", form)
-        ctx.set_tuning("force_general_q", general)   # 0: the specialised kinds (tables of 1/W per byte value), 1: the general kernel
+        ctx.set_reproject_form(form)
+        ctx.set_test_hook("force_general_q", general)   # 0: the specialised kinds (tables of 1/W per byte value), 1: the general kernel
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
         for fused in ((2, 1, 0) if mode == d2pc.MODE_COMPACT else (1, 0)):
@@ -599,7 +599,7 @@ def test_tile_fused_compact_kernel_matches_the_two_launches_and_the_oracle(gener
     src = torch.from_numpy(imgs).cuda()
     res = {}
     with d2pc.Context(q=q, border=border, mode=d2pc.MODE_COMPACT) as ctx:
-        ctx.set_tuning("force_general_q", general_q)
+        ctx.set_test_hook("force_general_q", general_q)
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
         s = torch.cuda.current_stream().cuda_stream

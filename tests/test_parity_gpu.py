@@ -46,7 +46,7 @@ def test_golden_exact_rational(golden, name):
     disp = golden[name + "__disp"]
     with ctx_for(q, border=border) as ctx:
         got = ctx.process(disp)
-        ctx.set_tuning("general_q_form", 1)   # round 2's fused multiply-add evaluation of a general Q
+        ctx.set_test_hook("general_q_form", 1)   # round 2's fused multiply-add evaluation of a general Q
         got_fma = ctx.process(disp)
     if name.endswith("dense_q"):
         # a GENERAL Q is evaluated in OpenCV 3/4's association, bit for bit (oracle FORM_CV4): two casts => within
@@ -290,7 +290,7 @@ def test_general_and_stereo_kernels_agree_bitwise(q_default):
     disp[100, 100:110] = [np.nan, np.inf, -np.inf, -1.0, 1e-30, 3e38, 0.0, -0.0, 1e-45, 5.0]
     with ctx_for(q_default) as ctx:
         a = ctx.process(disp)
-        ctx.set_tuning("force_general_q", 1)
+        ctx.set_test_hook("force_general_q", 1)
         b4 = ctx.process(disp)
         w4 = oracle.reproject(disp, q_default, border=40, form=oracle.FORM_CV4)
         nan4 = np.isnan(w4)
@@ -300,11 +300,11 @@ def test_general_and_stereo_kernels_agree_bitwise(q_default):
         wc4, wi4 = oracle.reproject_compact(disp, q_default, border=40, form=oracle.FORM_CV4)
         assert np.array_equal(i4, wi4) and np.array_equal(c4.view(np.uint32), wc4.view(np.uint32))
         ctx.set_mode(d2pc.MODE_PARITY)
-        ctx.set_tuning("general_q_form", 1)
+        ctx.set_test_hook("general_q_form", 1)
         b = ctx.process(disp)
         ctx.set_mode(d2pc.MODE_COMPACT)
         cg, ig = ctx.process(disp, want_index=True)
-        ctx.set_tuning("force_general_q", 0)
+        ctx.set_test_hook("force_general_q", 0)
         cs, i_s = ctx.process(disp, want_index=True)
     nan = np.isnan(a)
     assert np.array_equal(nan, np.isnan(b)) and nan.sum() >= 9  # NaN payloads may differ, NaN-ness may not
@@ -344,14 +344,14 @@ def test_reproject_form_selects_one_opencv_generation_bit_for_bit(w, h, border, 
         for general in (0, 1):
             with ctx_for(q, border=border) as ctx:
                 ctx.set_reproject_form(form)
-                ctx.set_tuning("force_general_q", general)
+                ctx.set_test_hook("force_general_q", general)
                 _same_bits(ctx.process(disp), want, f"form {form} general={general} {w}x{h}")
                 ctx.set_tuning("pxt_parity", 8)   # the tile-walking kernel too
                 _same_bits(ctx.process(disp), want, f"form {form} general={general} {w}x{h} (tiles)")
             for algo in (1, 2, 3, 4):
                 with ctx_for(q, border=border, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
                     ctx.set_reproject_form(form)
-                    ctx.set_tuning("force_general_q", general)
+                    ctx.set_test_hook("force_general_q", general)
                     gp, gi = ctx.process(disp, want_index=True)
                 assert np.array_equal(gi, wi)
                 _same_bits(gp, wp, f"compact (algo {algo}) form {form} general={general} {w}x{h}")
@@ -363,7 +363,7 @@ def test_reproject_form_24_u8_and_scale(q_default):
     img = rng.integers(0, 256, size=(480, 752)).astype(np.uint8)
     want = oracle.reproject(img, q_default, border=40, scale=0.125, form=oracle.FORM_CV24)
     with ctx_for(q_default) as ctx:
-        ctx.set_tuning("reproject_form", 24)
+        ctx.set_reproject_form(24)
         _same_bits(ctx.process(img, scale=0.125), want, "u8 x 1/8, 2.4 form")
     with ctx_for(q_default) as ctx:
         base = ctx.process(img, scale=0.125)
@@ -376,7 +376,7 @@ def test_reproject_form_24_refuses_a_q_without_exact_column_steps():
     q[12:16] = [2e-4, 1e-4, 0.03, 0.7]
     disp = np.ones((50, 60), dtype=np.float32)
     with ctx_for(q, border=0) as ctx:
-        ctx.set_tuning("reproject_form", 24)
+        ctx.set_reproject_form(24)
         with pytest.raises(d2pc.D2pcError) as e:
             ctx.process(disp)
         assert e.value.status == 1 and "column" in str(e.value)
@@ -389,7 +389,7 @@ def test_reproject_form_24_refuses_a_q_without_exact_column_steps():
     qa, qb = d2pc.make_q(cx=100.3), d2pc.make_q(cx=517.77)
     disp = synth_disparity(3, 5, 700, 90, "k8")
     with ctx_for(qa, border=0) as ctx:
-        ctx.set_tuning("reproject_form", 24)
+        ctx.set_reproject_form(24)
         _same_bits(ctx.process(disp), oracle.reproject(disp, qa, border=0), "first Q")
         ctx.set_q(qb)
         _same_bits(ctx.process(disp), oracle.reproject(disp, qb, border=0), "second Q")

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--ooffs", default="0", help="output base offset in points (several: A/B)")
     ap.add_argument("--small", type=int, default=None, help="tuning parity_small (1: one-shot blocks also for pxt 4)")
     ap.add_argument("--forms", default="0", help="tuning reproject_form (0 per Q kind, 24 / 4: one OpenCV generation bit for bit)")
+    ap.add_argument("--tunes", default="", help="alternatives separated by ';', each a comma-separated list of d2pc_set_tuning key=value (e.g. 'chunk_mb=96;chunk_mb=48,chunk_first_frames=1')")
     ap.add_argument("--w", type=int, default=3840)
     ap.add_argument("--h", type=int, default=2160)
     a = ap.parse_args()
@@ -74,7 +75,7 @@ def main():
 
     for lib in a.libs.split(","):
         L = load_variant(lib)
-        for mode, border, pxt, bpc, nv, algo, oal, oof, form in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(","), oaligns, ooffs, a.forms.split(",")):
+        for mode, border, pxt, bpc, nv, algo, oal, oof, form, tune in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(","), oaligns, ooffs, a.forms.split(","), a.tunes.split(";")):
             m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
             ctx = capi.Context(q=capi.make_q(), border=int(border), mode=m, compact_algo=int(algo))
             ctx.set_tuning("pxt_parity", int(pxt))
@@ -83,15 +84,18 @@ def main():
             if a.small is not None:
                 ctx.set_tuning("parity_small", a.small)
             if int(form):
-                ctx.set_tuning("reproject_form", int(form))
+                ctx.set_reproject_form(int(form))
             ctx.set_tuning("blocks_per_cu", int(bpc)); ctx.set_tuning("no_vec_rows", int(nv))
             ctx.set_tuning("onepass_blocks_per_cu", a.opbpc)
+            for kv in filter(None, tune.split(",")):
+                k, v = kv.split("=")
+                ctx.set_tuning(k, int(v))
             b = Cand(ctx, oal, oof)
             b.launch(); torch.cuda.synchronize()
             npts = int(counts.sum().item())
             roi_n = capi.roi_points(W, H, int(border))
             alg = 4 * F * roi_n + (20 if a.idx else 16) * npts
-            cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo} oalign={oal} ooff={oof} form={form}", b, alg, []))
+            cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo} oalign={oal} ooff={oof} form={form} {tune}", b, alg, []))
     for r in range(a.rounds):
         for label, b, alg, ts in cands:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -53,7 +53,7 @@ for c in range(cases):
     fgen = bool(stereo and rng.random() < 0.3)   # stereoRectify's Q through the general kernel (the other route to the same bytes)
     with d2pc.Context(q=q, border=border, mode=m, compact_algo=algo) as ctx:
         ctx.set_reproject_form(rform)
-        ctx.set_tuning("force_general_q", int(fgen))
+        ctx.set_test_hook("force_general_q", int(fgen))
         if algo == 4:
             ctx.set_tuning("chunk_mb", int(rng.choice([1, 2, 96])))
         b = DeviceBatch(ctx, n, h, w, dtype=tdt, want_index=idx)

@@ -48,7 +48,7 @@ for c in range(cases):
     forms = (2, 1, 0) if compact else (1, 0)
     rform = int(rng.choice([0, 0, 24, 4]))   # d2pc_set_reproject_form: one OpenCV generation bit for bit
     with d2pc.Context(q=q, border=border, mode=d2pc.MODE_COMPACT if compact else d2pc.MODE_PARITY) as ctx:
-        ctx.set_tuning("force_general_q", general)
+        ctx.set_test_hook("force_general_q", general)
         ctx.set_reproject_form(rform)
         ctx.set_tuning("median_algo", 2)
         b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=want_idx)
