@@ -84,9 +84,11 @@ struct d2pc_ctx {
   int parity_small = 0;          // PARITY kernel form: 0 = choose, 1 = one-shot blocks of 256 * pxt pixels (pxt 1, 2, 4), 2 = tiles walked by fewer blocks
   int blocks_per_cu = 128;
   int onepass_blocks_per_cu = 0;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each: 4 fit); 0 = choose per launch
-  int big_batch_algo = 4;          // COMPACT launches of >= 4 frames and >= 24,576 tiles: 4 = chunked two-pass of one-shot blocks, 2 = single pass
+  int big_batch_algo = 2;          // COMPACT launches of >= 4 frames and >= 24,576 tiles: 2 = single pass (default: faster), 4 = chunked two-pass of one-shot blocks
   int chunk_mb = 96;               // algo 4: input bytes per chunk (MiB); the chunk must stay in the 256 MiB Infinity Cache for one launch
   int chunk_first_frames = 0;      // algo 4: frames of the first chunk (0 = an eighth of a chunk)
+  int resident_unbounded = 0;      // algo 3, experiment: admit launches of more blocks than are resident at once (see enqueue)
+  int resident_pxt = 0;            // algo 3: pixels per thread of its blocks (0 = choose: the ordinary tile if the launch fits, else 32, else 64)
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
   int general_q_form = 0;        // 0: OpenCV 3/4's association bit for bit; 1: fused multiply-adds (round 2's form)
@@ -542,11 +544,34 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   const bool big_batch = g.n_frames >= 4 && g.total_tiles >= 24576;
   // camera-size launches whose tiles are all resident at once take ONE launch (k_compact_resident) unless the call
   // is being captured (its epoch argument would freeze in the graph); one 1080p frame 16 -> ~8 us
-  const bool resident_ok = g.total_tiles <= uint32_t(ctx->cu_count * kResidentBlocksPerCu) && g.tiles_per_frame <= 1024u &&
-                           !capture_info(stream, nullptr);
+  // ... in the ordinary tiles (k_compact_resident), or -- one or two 4K frames -- in blocks of 32 / 64 pixels per thread
+  // that keep their disparities in registers between count and scatter (k_compact_resident_lean)
+  const uint32_t resident_cap = uint32_t(ctx->cu_count * kResidentBlocksPerCu);
+  const bool not_captured = !capture_info(stream, nullptr);
+  int resident_pxt = 0;
+  for (int r : {int(g.pxt), 32, 64}) {
+    const uint32_t tpf = (g.roi_n + uint32_t(kBlock * r) - 1u) / uint32_t(kBlock * r);
+    if (!resident_pxt && uint64_t(tpf) * g.n_frames <= resident_cap && tpf <= 1024u) resident_pxt = r;
+  }
+  if (ctx->resident_pxt) {  // (tuning: force one of the shapes where it fits)
+    const int r = ctx->resident_pxt;
+    const uint32_t tpf = (g.roi_n + uint32_t(kBlock * r) - 1u) / uint32_t(kBlock * r);
+    // EXPERIMENT "resident_unbounded": more blocks than fit at once.  A block waits for lower-numbered blocks of its frame
+    // only, so this is safe exactly if every XCD starts its share of the grid in index order (then the lowest unfinished
+    // block always runs); the time-out turns a violation into kCountTimedOut, not a hang
+    const bool fits = uint64_t(tpf) * g.n_frames <= resident_cap || (ctx->resident_unbounded && r >= 32 && uint64_t(tpf) * g.n_frames <= 0x7fffffffull);
+    resident_pxt = (fits && (tpf <= 1024u || ctx->resident_unbounded)) ? r : 0;
+  }
+  const bool resident_ok = resident_pxt != 0 && not_captured;
   const int dflt = big_batch ? ctx->big_batch_algo : resident_ok ? 3 : 1;
   a.compact_algo = force_algo ? force_algo : ctx->cfg.compact_algo ? ctx->cfg.compact_algo : dflt;
   if (a.compact_algo == 3 && !resident_ok) a.compact_algo = big_batch ? ctx->big_batch_algo : 1;  // (asked for, not possible here)
+  if (a.compact_algo == 3 && resident_pxt != int(g.pxt)) {
+    Geom gr = g;
+    retile(&gr, resident_pxt);
+    a.geom = gr;
+    a.pxt = resident_pxt;
+  }
   if (a.compact_algo == 4) {
     // chunked two-pass (k_compact_chunk): the geometry in its own 512-pixel tiles; chunks of whole frames whose input
     // stays in the Infinity Cache between the launch that counts it and the launch that scatters it
@@ -578,7 +603,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     if (a.grid < g.n_frames) a.compact_algo = 1;  // more frames than blocks: every block serves one frame only
   }
   if (a.compact_algo == 3) {
-    a.grid = g.total_tiles;
+    a.grid = a.geom.total_tiles;
     a.epoch = ctx->resident_epoch++;
     if (ctx->resident_epoch >= kEpochEnd) {  // (once in 2^30 launches: start over from clean state)
       ctx->resident_epoch = kEpochBase;
@@ -989,6 +1014,8 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "big_batch_algo") && (value == 2 || value == 4)) ctx->big_batch_algo = value;
+  else if (!strcmp(key, "resident_unbounded") && (value == 0 || value == 1)) ctx->resident_unbounded = value;
+  else if (!strcmp(key, "resident_pxt") && (value == 0 || value == 32 || value == 64 || tile_shape_supported(value))) ctx->resident_pxt = value;
   else if (!strcmp(key, "chunk_mb") && value >= 1 && value <= 4096) ctx->chunk_mb = value;
   else if (!strcmp(key, "chunk_first_frames") && value >= 0 && value <= 65535) ctx->chunk_first_frames = value;
   else if (!strcmp(key, "callback_chunks") && value >= 0 && value <= 64) ctx->cb_chunks = value;

@@ -54,9 +54,17 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifndef D2PC_SCATTER_STORE_NT
 #define D2PC_SCATTER_STORE_NT 1
 #endif
-// chunked two-pass (compact_algo 4): point and index stores of its one-shot scatter blocks
+// chunked two-pass (compact_algo 4) and the register-resident one-launch form (k_compact_resident_lean): point and index
+// stores of their ragged pieces.  PLAIN: a piece of K x 16 bytes starts and ends inside 64-byte lines that the
+// neighbouring pieces complete, and L2 must keep those lines to merge them -- tools/membench11.hip, 30 % holes: 5.49 TB/s
+// plain against 4.27 nt (rows re-blocked to whole lines: 5.59); moving the survivors to the low lanes changes nothing.
+// (the chunked two-pass keeps nt all the same: with plain stores its launches run 9-12 % slower, 568 vs 521 us per 16 x 4K
+// with 30 % holes + indices -- the output then competes with the chunk's input for the caches; profiles/r04_ab_store_nt.txt)
 #ifndef D2PC_CHUNK_STORE_NT
 #define D2PC_CHUNK_STORE_NT 1
+#endif
+#ifndef D2PC_RESIDENT_STORE_NT
+#define D2PC_RESIDENT_STORE_NT 0
 #endif
 #ifndef D2PC_CHUNK_INDEX_NT
 #define D2PC_CHUNK_INDEX_NT 0
@@ -1085,6 +1093,202 @@ __global__ __launch_bounds__(kBlock) void k_compact_resident(const uint8_t *__re
   tile_scatter<DT, QK, PXT>(r, mask, fout, fidx, s_prefix, excl, wave, lane, g.roi_n);
 }
 
+// W = a*d + b of a stereoRectify-structured Q decides validity without the point:
+//   finite and |W| >= w_safe            => every coordinate is a finite float          -> valid
+//   W zero, infinite or NaN (d = +-inf gives +-inf or NaN; no poisoning of d needed)    -> invalid
+//   0 < |W| < w_safe, the "sliver"      => only the real arithmetic can tell (never seen with a real
+//                                          calibration; a tile that holds one takes the exact path)
+template <int QK>
+__device__ __forceinline__ double stereo_nw(const QArg<QK> &A, float d) { return stereo_w(A, double(d)); }
+__device__ __forceinline__ bool finite_nonzero(double x) {
+  return __builtin_isfpclass(x, 0x0008 | 0x0010 | 0x0080 | 0x0100);  // -normal, -subnormal, +subnormal, +normal
+}
+
+// --------------------------------------------------------------------------
+// K2R: the same one-launch form for frames of more than 1,024 ordinary tiles (one or two 4K frames): a block takes R
+// pixels per thread -- 8,192 (R = 32) or 16,384 (R = 64) consecutive ROI pixels -- so that a 4K frame is 955 / 478 blocks
+// and the whole launch is still resident at once (one 4K frame in COMPACT mode used to take two launches and two reads of
+// its input: 41 us against 23 us PARITY).  The block's pixels stay in REGISTERS between the count and the scatter: only
+// the disparities (R dwords per lane, one coalesced 256-byte piece per wave and load, all requested before the first is
+// looked at); survivors are counted with the exact predicate (W = a*d + b for stereoRectify's Q, the real arithmetic for a
+// wave that meets a sliver or a general Q), the block publishes ONE epoch-tagged granule, sums those of its
+// predecessors in the frame (<= 1,023: all requested together), and then forms the points and stores them in order --
+// a wave owns 64 * R consecutive pixels, so every store instruction is still one contiguous piece of <= 1 KiB.
+// Epochs, time-outs and the residency rule are k_compact_resident's.
+// --------------------------------------------------------------------------
+// A value the compiler cannot relate to its source (no instruction is emitted): breaks common-subexpression reuse
+// where recomputing is cheaper than keeping.
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ float opaque(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+template <int DT, int QK, int R>
+__global__ __launch_bounds__(kBlock) void k_compact_resident_lean(const uint8_t *__restrict__ disp, float4 *__restrict__ out,
+                                                                  uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
+                                                                  uint8_t *state, CompactStats *stats, const Geom g, const QArg<QK> Q,
+                                                                  const uint32_t epoch) {
+  using gu64 = __attribute__((address_space(1))) uint64_t;
+  __shared__ uint32_t s_red[kBlock / 64];
+  __shared__ uint32_t s_prefix;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
+  const uint32_t t = blockIdx.x;
+  const uint32_t f = fdiv(t, g.div_tpf);
+  const uint32_t lt = t - f * g.tiles_per_frame;
+  const FrameState fs(state, g, f);
+  const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
+  const uint32_t i0 = lt * uint32_t(kBlock * R) + wave * uint32_t(64 * R) + lane;  // pixel k of the lane: i0 + 64 k
+  float d[R];
+  {
+    // coordinates stepped from slot to slot (rows wrap inside the run): one division per thread
+    Walker w(g, i0);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint32_t off = (w.v + g.border) * g.row_stride + (w.u + g.border) * elem_bytes<DT>();
+      d[k] = load_disparity<DT>(fin, off < g.last_off ? off : g.last_off, g.scale);
+      w.step(g, g.s64_v, g.s64_u);
+      __builtin_amdgcn_sched_barrier(0);  // (compiler fence only: addresses are formed one load at a time, not R at once)
+    }
+  }
+  // A frame's last block may reach past the ROI: those slots (their loads were clamped into the frame) become NaN, which
+  // every predicate below drops -- one block-uniform branch instead of a range test per slot in both phases (tests that
+  // depend on the lane only are hoisted and kept: 2 R scalar registers, spilled)
+  if (lt == g.tiles_per_frame - 1u) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) d[k] = i0 + uint32_t(k) * 64u < g.roi_n ? d[k] : __builtin_nanf("");
+  }
+  // ---- count ---- (per LANE, summed over the wave once: a ballot + popcount per slot left R masks waiting in scalar
+  // registers -- ~400 of them spilled at R = 64)
+  uint32_t cnt = 0;
+  bool exact = !is_stereo(QK);
+  if constexpr (is_stereo(QK)) {
+    uint32_t sl = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const double nw = stereo_nw(Q, d[k]);
+      const bool fin_ = finite_nonzero(nw), big = fabs(nw) >= Q.s.w_safe;
+      const bool keep = !(d[k] <= g.min_disparity);
+      cnt += uint32_t(bool(fin_ & big & keep));  // (& on bools: no short-circuit branches)
+      cnt = opaque(cnt);  // (the sum must advance slot by slot: reassociated into a tree, every slot's masks wait for the end)
+      sl = opaque(sl | uint32_t(bool(fin_ & !big)));
+    }
+    exact = __ballot(sl != 0u) != 0;
+  }
+  if (exact) {  // (wave-uniform) general Q, or a sliver: the real arithmetic decides, as the scatter below does
+    cnt = 0;
+    Walker w(g, opaque(i0));
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      float X, Y, Z;
+      reproject(Q, w.u + g.border, w.v + g.border, d[k], X, Y, Z);
+      cnt += uint32_t(point_is_valid(X, Y, Z, d[k], g.min_disparity));
+      cnt = opaque(cnt);
+      w.step(g, g.s64_v, g.s64_u);
+    }
+  }
+  const uint32_t total = wave_sum(cnt);  // wave-uniform
+  if (lane == 0) s_red[wave] = total;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < uint32_t(kBlock / 64); ++w) {
+    const uint32_t x = s_red[w];
+    before += w < wave ? x : 0u;
+    all += x;
+  }
+  // ---- publish, and the counts of the frame's blocks before this one ----
+  if (wave == 0) {
+    if (lane == 0)
+      __hip_atomic_store((gu64 *)(fs.granules + 2u * lt), (uint64_t(epoch) << 32) | all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t sum = 0, spins = 0;
+    uint64_t w0 = 0;
+    bool gave_up = false;
+    for (;;) {
+      bool ok = true;
+      sum = 0;
+      for (uint32_t b0 = 0; b0 < lt; b0 += 512u) {  // eight granules per lane and step, requested together
+        uint64_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t i = b0 + uint32_t(j) * 64u + lane;
+          v[j] = i < lt ? __hip_atomic_load((gu64 *)(fs.granules + 2u * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : (uint64_t(epoch) << 32);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ok = ok && uint32_t(v[j] >> 32) == epoch;
+          sum += uint32_t(v[j]);
+        }
+      }
+      if (__all(ok)) break;
+      if (spins == 0) w0 = __builtin_amdgcn_s_memrealtime();
+      backoff(spins);
+      ++spins;
+      if ((spins & 7u) == 0 && (__builtin_amdgcn_s_memrealtime() - w0 > uint64_t(g.spin_ticks) ||
+                                __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)) {
+        if (lane == 0 && __hip_atomic_exchange(&hdr->timeout, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+          atomicAdd(&stats->timeouts, 1ull);
+        gave_up = true;
+        break;
+      }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) {
+      s_prefix = sum;
+      if (lt == g.tiles_per_frame - 1u) {
+        const bool broken = gave_up || __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+        __hip_atomic_store(counts + f, broken ? kCountTimedOut : sum + all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (gave_up) {
+        __hip_atomic_store(counts + f, kCountTimedOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#if D2PC_ONEPASS_STATS
+      if (spins) {
+        CompactStats::Slot *sl = stats->slot + (blockIdx.x % uint32_t(kStatSlots));
+        atomicAdd(&sl->failed_polls, (unsigned long long)spins);
+        atomicAdd(&sl->wait_ticks, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - w0));
+      }
+      if (t == 0) {
+        atomicAdd(&stats->launches, 1ull);
+        atomicAdd(&stats->slot[0].tiles, (unsigned long long)g.total_tiles);
+      }
+#endif
+    }
+  }
+  __syncthreads();
+  // ---- the points, in order ----
+  float4 *fout = out + uint64_t(f) * g.out_frame_stride;
+  uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
+  uint32_t pos = s_prefix + before;
+  // (opaque: the coordinates are stepped AGAIN here; left to itself the compiler keeps the R coordinate pairs of the load
+  // loop alive across the whole kernel instead -- 3 R registers per lane, 222 VGPRs at R = 64)
+  // (the same for the disparities: sub-masks of the count's predicate -- d <= min_disparity, pixel < roi_n -- would be kept
+  // for every slot: 2 R scalar register pairs, spilled)
+  Walker w(g, opaque(i0));
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const uint32_t uu = w.u + g.border, vv = w.v + g.border;
+    const float dk = opaque(d[k]);
+    float X, Y, Z;
+    reproject(Q, uu, vv, dk, X, Y, Z);
+    const bool ok = point_is_valid(X, Y, Z, dk, g.min_disparity);
+    const uint64_t m = __ballot(ok);
+    const uint32_t p = pos + mbcnt64(m);
+    // p < roi_n always holds for a correct prefix; the guard keeps a timed-out prefix from becoming an out-of-bounds store
+    if (ok && p < g.roi_n) {
+      store_point<D2PC_RESIDENT_STORE_NT != 0>(fout, p, X, Y, Z);
+      if (fidx) store_index(fidx, p, vv * g.width + uu);
+    }
+    pos += uint32_t(__popcll(m));
+    w.step(g, g.s64_v, g.s64_u);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // --------------------------------------------------------------------------
 // K2c: CHUNKED two-pass compaction (compact_algo 4) for big batches: one-shot blocks only, nothing waits inside a launch.
 //
@@ -1123,17 +1327,6 @@ struct ChunkFrameState {
     rp = gpre + c.gsum_words;
   }
 };
-
-// W = a*d + b of a stereoRectify-structured Q decides validity without the point:
-//   finite and |W| >= w_safe            => every coordinate is a finite float          -> valid
-//   W zero, infinite or NaN (d = +-inf gives +-inf or NaN; no poisoning of d needed)    -> invalid
-//   0 < |W| < w_safe, the "sliver"      => only the real arithmetic can tell (never seen with a real
-//                                          calibration; a tile that holds one takes the exact path)
-template <int QK>
-__device__ __forceinline__ double stereo_nw(const QArg<QK> &A, float d) { return stereo_w(A, double(d)); }
-__device__ __forceinline__ bool finite_nonzero(double x) {
-  return __builtin_isfpclass(x, 0x0008 | 0x0010 | 0x0080 | 0x0100);  // -normal, -subnormal, +subnormal, +normal
-}
 
 // validity of the pixel (image coordinates uu, vv; disparity d) exactly as the scatter blocks decide it
 template <int QK>
@@ -1192,19 +1385,29 @@ __device__ __forceinline__ uint32_t chunk_count_wave(const uint8_t *fin, const G
       // the real arithmetic instead.  Runs are accounted for piece by piece (no array of counts waits in scalar registers).
       const uint32_t total0 = total, mine0 = mine;
       uint64_t sliver = 0;
+      // the frame's last group may reach past the ROI: those pixels (their loads were clamped into the frame) become NaN,
+      // which the predicate drops -- a range test per pixel would be hoisted and its 32 masks kept in scalar registers
+      if ((run0 + r0 + kWaveRuns / 2u) * kChunkRun > g.roi_n) {  // (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          const int32_t left = int32_t(g.roi_n - (i00 + uint32_t(j) * 256u));  // the frame's pixels from this lane's group on (<= 0: none)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[j][e] = e < left ? q[j][e] : __builtin_nanf("");
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        const int32_t left = int32_t(g.roi_n - (i00 + uint32_t(j) * 256u));  // the frame's pixels from this lane's group on (<= 0: none)
         uint32_t lo = 0, hi = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float d = q[j][e];
           const double nw = stereo_nw(Q, d);
           const bool fin_ = finite_nonzero(nw), big = fabs(nw) >= Q.s.w_safe;
-          const uint64_t m = __ballot(int(fin_) & int(big) & int(!(d <= g.min_disparity)) & int(e < left));
+          const bool keep = !(d <= g.min_disparity);
+          const uint64_t m = __ballot(bool(fin_ & big & keep));  // (& on bools: no short-circuit branches)
           lo += uint32_t(__builtin_popcount(uint32_t(m)));
           hi += uint32_t(__builtin_popcount(uint32_t(m >> 32)));
-          sliver |= __ballot(int(fin_) & int(!big));
+          sliver |= __ballot(bool(fin_ & !big));
         }
         mine = lane == r0 + 2u * uint32_t(j) ? total : mine;
         total += lo;
@@ -2479,6 +2682,10 @@ size_t compact_state_bytes(const Geom &g) {
 }
 
 static hipError_t dispatch(const LaunchArgs &a, bool compact) {
+#ifdef D2PC_FOCUS  // `make asm-focus`: only the kernels under development are instantiated (seconds instead of minutes)
+  (void)a; (void)compact;
+  return hipErrorNotSupported;
+#else
   if (!compact && a.parity_small) {  // the small one-shot tiles (PARITY only)
 #define D2PC_SMALL(S)                                                          \
   switch (a.q_kind) {                                                          \
@@ -2502,9 +2709,14 @@ static hipError_t dispatch(const LaunchArgs &a, bool compact) {
     case 16: return dispatch_q<16>(a, compact);
   }
   return hipErrorInvalidValue;
+#endif
 }
 
 hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src, int ksize) {
+#ifdef D2PC_FOCUS
+  (void)a; (void)m; (void)src; (void)ksize;
+  return hipErrorNotSupported;
+#else
   if (!median_ksize_supported(ksize) || m.out_w == 0 || m.out_h == 0) return hipErrorInvalidValue;
   if (m.out_x0 != a.geom.border || m.out_y0 != a.geom.border || m.out_w != a.geom.roi_w ||
       uint64_t(m.out_w) * m.out_h != a.geom.roi_n)
@@ -2545,6 +2757,7 @@ hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src
   }
 #undef D2PC_CB_BS
   return hipGetLastError();
+#endif
 }
 
 size_t callback_compact_state_bytes(uint32_t tiles_x, uint32_t tiles_y, uint32_t n_frames, uint32_t *frame_stride) {
@@ -2555,6 +2768,10 @@ size_t callback_compact_state_bytes(uint32_t tiles_x, uint32_t tiles_y, uint32_t
 }
 
 hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const void *src, int ksize) {
+#ifdef D2PC_FOCUS
+  (void)a; (void)m; (void)src; (void)ksize;
+  return hipErrorNotSupported;
+#else
   if (!median_ksize_supported(ksize) || m.out_w == 0 || m.out_h == 0 || !a.state || !a.stats || !a.counts) return hipErrorInvalidValue;
   if (m.out_x0 != a.geom.border || m.out_y0 != a.geom.border || m.out_w != a.geom.roi_w ||
       uint64_t(m.out_w) * m.out_h != a.geom.roi_n)
@@ -2613,9 +2830,42 @@ hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const v
   }
 #undef D2PC_CB_BSC
   return hipGetLastError();
+#endif
 }
 
 hipError_t launch_parity(const LaunchArgs &a) { return dispatch(a, false); }
-hipError_t launch_compact(const LaunchArgs &a) { return a.compact_algo == 4 ? launch_compact_chunked(a) : dispatch(a, true); }
+template <int QK, int R>
+static hipError_t launch_resident_lean_q(const LaunchArgs &a) {
+#define D2PC_RL(DT)                                                                                                             \
+  hipLaunchKernelGGL((k_compact_resident_lean<DT, QK, R>), dim3(a.grid), dim3(kBlock), 0, a.stream,                              \
+                     static_cast<const uint8_t *>(a.disp), static_cast<float4 *>(a.out_points), a.out_index, a.counts,           \
+                     static_cast<uint8_t *>(a.state), static_cast<CompactStats *>(a.stats), a.geom, make_qarg<QK>(a), a.epoch)
+  switch (a.dtype) {
+    case DT_F32: D2PC_RL(DT_F32); break;
+    case DT_U8: D2PC_RL(DT_U8); break;
+    case DT_U16: D2PC_RL(DT_U16); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef D2PC_RL
+  return hipGetLastError();
+}
+template <int R>
+static hipError_t launch_resident_lean(const LaunchArgs &a) {
+  if (a.grid != a.geom.total_tiles || !a.stats || a.epoch < kEpochBase || a.geom.pxt != uint32_t(R)) return hipErrorInvalidValue;
+  switch (a.q_kind) {
+    case QK_STEREO: return launch_resident_lean_q<QK_STEREO, R>(a);
+    case QK_STEREO_CV24: return launch_resident_lean_q<QK_STEREO_CV24, R>(a);
+    case QK_STEREO_CV4: return launch_resident_lean_q<QK_STEREO_CV4, R>(a);
+    case QK_GENERAL: return launch_resident_lean_q<QK_GENERAL, R>(a);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_compact(const LaunchArgs &a) {
+  if (a.compact_algo == 4) return launch_compact_chunked(a);
+  if (a.compact_algo == 3 && a.pxt == 32) return launch_resident_lean<32>(a);
+  if (a.compact_algo == 3 && a.pxt == 64) return launch_resident_lean<64>(a);
+  return dispatch(a, true);
+}
 
 }  // namespace d2pc

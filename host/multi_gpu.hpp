@@ -4,8 +4,8 @@
 // 46-52: ros::init, construct, ros::spin); a maintainer with N cameras on one node has no Python.  This is that
 // deployment without ROS, in ONE process:
 //
-//   d2pc_replay --gpus N [--devices a,b,..] [--device D] [--frames F] [--width W --height H] [--encoding mono8|mono16]
-//               [--median K] [--compact] [--depth P] [--in frame.raw] [--out prefix] [name=value ...]
+//   d2pc_replay --gpus N [--devices a,b,..] [--device D] [--share-device] [--frames F] [--width W --height H]
+//               [--encoding mono8|mono16] [--median K] [--compact] [--depth P] [--in frame.raw] [--out prefix] [name=value ...]
 //               (name=value: the private parameters fx_ fy_ cx_ cy_ base_line_, and reproject_form=0|24|4)
 //
 //   * ncclCommInitAll over the N devices (RCCL; xGMI between the GPUs of a node)
@@ -18,6 +18,13 @@
 //
 // RCCL is resolved at run time (dlopen("librccl.so.1")): only this mode needs it; libd2pc.so and the
 // single-GPU commands of the harness stay free of it.  Never re-executes the process.
+//
+// REHEARSAL (--share-device): all N ranks on ONE device (the first of --devices, default 0) -- what a one-GPU box
+// allows.  RCCL refuses two ranks on a device, so the three collectives go through an in-process loopback that fills
+// the same function-pointer table dlsym fills (Loopback below: device-to-device copies for the broadcast, a host-side
+// sum for the all-reduce, every rank's part on that rank's stream).  Everything else is the real thing: N rank
+// threads, N contexts, N frame queues running concurrently, each configured from the blob it RECEIVED.  The report
+// line says "rehearsal_shared_device": it is a concurrency rehearsal of the deployment, never a scaling measurement.
 #pragma once
 #include <dlfcn.h>
 
@@ -27,6 +34,7 @@
 #include <cstring>
 #include <fstream>
 #include <random>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,6 +58,7 @@ struct Options {
   std::string in_path, out_prefix;
   double fx = 714.24, fy = 713.5, cx = 376, cy = 240, base_line = 0.09;  // hpp:66-71
   int reproject_form = 0;       // d2pc_set_reproject_form on every rank (0, 24, 4)
+  bool share_device = false;    // rehearsal: every rank on devices[0], collectives through the in-process loopback
   std::string error;            // non-empty: bad command line
 };
 
@@ -113,6 +122,9 @@ inline Options parse(int argc, char **argv) {
       if (!need(i)) bad("expects a path prefix"); else o.out_prefix = argv[++i];
     } else if (a == "--compact") {
       o.compact = true;
+    } else if (a == "--share-device") {
+      multi = true;
+      o.share_device = true;
     } else if (a.find('=') != std::string::npos) {  // private parameters, as a launch file would set them (hpp:84-88)
       const size_t eq = a.find('=');
       const std::string k = a.substr(0, eq);
@@ -137,9 +149,18 @@ inline Options parse(int argc, char **argv) {
     o.gpus = 1;
     o.devices.assign(1, single_device);
   }
-  if (!o.devices.empty() && o.gpus == 0) o.gpus = int(o.devices.size());
+  if (!o.devices.empty() && o.gpus == 0 && !o.share_device) o.gpus = int(o.devices.size());
   if (o.gpus == 0 && o.error.empty()) o.error = "--gpus N missing";
-  if (!o.devices.empty() && int(o.devices.size()) != o.gpus && o.error.empty()) o.error = "--devices lists another number of GPUs than --gpus";
+  if (!o.share_device && !o.devices.empty() && int(o.devices.size()) != o.gpus && o.error.empty()) o.error = "--devices lists another number of GPUs than --gpus";
+  if (o.share_device) {  // rehearsal: N ranks on the first listed device (default 0)
+    if (single_device >= 0 && o.error.empty()) o.error = "--share-device goes with --gpus N (and optionally --devices D): --device D means one rank";
+    const int d = o.devices.empty() ? 0 : o.devices[0];
+    if (o.devices.size() > 1 && o.error.empty()) o.error = "--share-device takes ONE device (--devices D)";
+    if (o.gpus == 0 && o.error.empty()) o.error = "--gpus N missing";
+    if (o.gpus > 16 && o.error.empty()) o.error = "--share-device rehearses at most 16 ranks on a device";
+    o.devices.assign(size_t(o.gpus > 0 ? o.gpus : 1), d);
+    return o;
+  }
   if (o.devices.empty())
     for (int i = 0; i < o.gpus; ++i) o.devices.push_back(i);
   for (size_t i = 0; i < o.devices.size(); ++i)
@@ -182,7 +203,159 @@ struct Rccl {
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
     return error.empty();
   }
+  bool load_loopback();  // --share-device: the same table, filled with the in-process loopback (below)
 };
+
+// ---- in-process loopback of the three collectives (--share-device) --------------------------------------------
+// Same signatures as RCCL's, same call pattern (ncclCommInitAll, then grouped per-rank calls between ncclGroupStart
+// and ncclGroupEnd, each rank's call on its own stream).  A "communicator" is a small record; the grouped calls are
+// collected and carried out at ncclGroupEnd, when every rank's buffers are known:
+//   broadcast   the root's buffer is copied device-to-device into every other rank's, on that rank's stream
+//   all-reduce  (ncclUint64, ncclSum) every rank's input is read back, summed on the host, and the sum is copied into
+//               every rank's output on its stream
+// One world per process (the harness makes one); calls come from the thread that runs d2pc_multi::run.
+namespace loopback {
+struct Comm {
+  int rank = 0, n = 0;
+};
+struct Call {
+  int kind = 0;  // 1 broadcast, 2 all-reduce
+  const void *send = nullptr;
+  void *recv = nullptr;
+  size_t count = 0;
+  ncclDataType_t type = ncclUint8;
+  int root = 0;
+  Comm *comm = nullptr;
+  hipStream_t stream = nullptr;
+};
+struct World {
+  std::mutex mu;
+  std::vector<Comm *> comms;
+  std::vector<Call> pending;
+  int depth = 0;
+  std::string last_error;
+};
+inline World &world() {
+  static World w;
+  return w;
+}
+inline ncclResult_t fail(const std::string &why) {
+  world().last_error = why;
+  return ncclInvalidUsage;
+}
+inline ncclResult_t CommInitAll(ncclComm_t *comms, int n, const int *devs) {
+  (void)devs;
+  if (!comms || n < 1) return fail("loopback: bad ncclCommInitAll arguments");
+  std::lock_guard<std::mutex> lock(world().mu);
+  for (int r = 0; r < n; ++r) {
+    Comm *c = new Comm{r, n};
+    world().comms.push_back(c);
+    comms[r] = reinterpret_cast<ncclComm_t>(c);
+  }
+  return ncclSuccess;
+}
+inline ncclResult_t CommDestroy(ncclComm_t comm) {
+  std::lock_guard<std::mutex> lock(world().mu);
+  Comm *c = reinterpret_cast<Comm *>(comm);
+  for (Comm *&x : world().comms)
+    if (x == c) {
+      delete c;
+      x = nullptr;
+      return ncclSuccess;
+    }
+  return fail("loopback: unknown communicator");
+}
+inline ncclResult_t GroupStart() {
+  std::lock_guard<std::mutex> lock(world().mu);
+  ++world().depth;
+  return ncclSuccess;
+}
+inline size_t type_bytes(ncclDataType_t t) { return t == ncclUint64 || t == ncclInt64 || t == ncclFloat64 ? 8 : t == ncclUint8 || t == ncclInt8 ? 1 : 4; }
+inline ncclResult_t flush(World &w) {
+  std::vector<Call> calls;
+  calls.swap(w.pending);
+  if (calls.empty()) return ncclSuccess;
+  const int n = calls[0].comm->n;
+  if (int(calls.size()) != n) return fail("loopback: a collective needs one call per rank inside the group");
+  std::vector<const Call *> by_rank(size_t(n), nullptr);
+  for (const Call &c : calls) {
+    if (c.kind != calls[0].kind || c.count != calls[0].count || c.type != calls[0].type || c.root != calls[0].root || c.comm->n != n)
+      return fail("loopback: the ranks disagree about the collective");
+    if (by_rank[size_t(c.comm->rank)]) return fail("loopback: a rank called twice");
+    by_rank[size_t(c.comm->rank)] = &c;
+  }
+  const size_t bytes = calls[0].count * type_bytes(calls[0].type);
+  if (calls[0].kind == 1) {
+    const Call &root = *by_rank[size_t(calls[0].root)];
+    if (hipStreamSynchronize(root.stream) != hipSuccess) return ncclUnhandledCudaError;  // the root's bytes are final
+    for (int r = 0; r < n; ++r) {
+      const Call &c = *by_rank[size_t(r)];
+      if (c.recv != root.send && hipMemcpyAsync(c.recv, root.send, bytes, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
+        return ncclUnhandledCudaError;
+    }
+    return ncclSuccess;
+  }
+  if (calls[0].type != ncclUint64) return fail("loopback: the all-reduce rehearsal handles ncclUint64 sums only");
+  std::vector<unsigned long long> sum(calls[0].count, 0ull), part(calls[0].count);
+  for (int r = 0; r < n; ++r) {
+    const Call &c = *by_rank[size_t(r)];
+    if (hipStreamSynchronize(c.stream) != hipSuccess || hipMemcpy(part.data(), c.send, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+      return ncclUnhandledCudaError;
+    for (size_t i = 0; i < sum.size(); ++i) sum[i] += part[i];
+  }
+  for (int r = 0; r < n; ++r) {
+    const Call &c = *by_rank[size_t(r)];
+    // (pageable source: the copy has left the host buffer when the call returns)
+    if (hipMemcpyAsync(c.recv, sum.data(), bytes, hipMemcpyHostToDevice, c.stream) != hipSuccess || hipStreamSynchronize(c.stream) != hipSuccess)
+      return ncclUnhandledCudaError;
+  }
+  return ncclSuccess;
+}
+inline ncclResult_t GroupEnd() {
+  std::lock_guard<std::mutex> lock(world().mu);
+  World &w = world();
+  if (w.depth <= 0) return fail("loopback: ncclGroupEnd without ncclGroupStart");
+  if (--w.depth > 0) return ncclSuccess;
+  return flush(w);
+}
+inline ncclResult_t enqueue(const Call &c) {
+  std::lock_guard<std::mutex> lock(world().mu);
+  World &w = world();
+  w.pending.push_back(c);
+  if (w.depth == 0) return c.comm->n == 1 ? flush(w) : fail("loopback: several ranks in one process call inside a group");
+  return ncclSuccess;
+}
+inline ncclResult_t Broadcast(const void *send, void *recv, size_t count, ncclDataType_t type, int root, ncclComm_t comm, hipStream_t stream) {
+  Comm *c = reinterpret_cast<Comm *>(comm);
+  if (!c || !recv || root < 0 || root >= c->n) return fail("loopback: bad ncclBroadcast arguments");
+  Call k;
+  k.kind = 1; k.send = send; k.recv = recv; k.count = count; k.type = type; k.root = root; k.comm = c; k.stream = stream;
+  return enqueue(k);
+}
+inline ncclResult_t AllReduce(const void *send, void *recv, size_t count, ncclDataType_t type, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream) {
+  Comm *c = reinterpret_cast<Comm *>(comm);
+  if (!c || !send || !recv || op != ncclSum) return fail("loopback: bad ncclAllReduce arguments (sums only)");
+  Call k;
+  k.kind = 2; k.send = send; k.recv = recv; k.count = count; k.type = type; k.root = 0; k.comm = c; k.stream = stream;
+  return enqueue(k);
+}
+inline const char *GetErrorString(ncclResult_t r) {
+  static thread_local std::string s;
+  s = "loopback collective failed (" + std::to_string(int(r)) + "): " + world().last_error;
+  return s.c_str();
+}
+}  // namespace loopback
+
+inline bool Rccl::load_loopback() {
+  CommInitAll = &loopback::CommInitAll;
+  CommDestroy = &loopback::CommDestroy;
+  Broadcast = &loopback::Broadcast;
+  AllReduce = &loopback::AllReduce;
+  GroupStart = &loopback::GroupStart;
+  GroupEnd = &loopback::GroupEnd;
+  GetErrorString = &loopback::GetErrorString;
+  return true;
+}
 
 struct RankResult {
   unsigned long long counters[4] = {0, 0, 0, 0};  // frames, pixels, points, busy nanoseconds
@@ -326,7 +499,7 @@ inline int run(const Options &o) {
     }
   }
   Rccl rccl;
-  if (!rccl.load()) {
+  if (o.share_device ? !rccl.load_loopback() : !rccl.load()) {
     fprintf(stderr, "d2pc_replay --gpus: %s\n", rccl.error.c_str());
     return 7;
   }
@@ -432,13 +605,14 @@ inline int run(const Options &o) {
       ++failed;
     }
   }
-  printf("{\"n_gpus\": %d, \"devices\": [", n);
+  printf("{\"n_gpus\": %d, %s\"devices\": [", n, o.share_device ? "\"rehearsal_shared_device\": true, " : "");
   for (int r = 0; r < n; ++r) printf("%s%d", r ? ", " : "", o.devices[size_t(r)]);
   printf("], \"frames\": %llu, \"pixels\": %llu, \"points\": %llu, \"busy_ns_sum\": %llu, \"wall_s\": %.6f, "
          "\"Mpixels_per_s\": %.1f, \"what\": \"%dx%d %s, median %d, %s, pipeline depth %d, PCIe-inclusive host path; "
-         "calibration by ncclBroadcast, counters by ncclAllReduce\", \"per_rank_frames\": [",
+         "calibration by ncclBroadcast, counters by ncclAllReduce%s\", \"per_rank_frames\": [",
          total[0], total[1], total[2], total[3], wall, wall > 0 ? double(total[1]) / wall / 1e6 : 0.0, o.width, o.height,
-         o.encoding.c_str(), o.median, o.compact ? "compact" : "parity", o.depth);
+         o.encoding.c_str(), o.median, o.compact ? "compact" : "parity", o.depth,
+         o.share_device ? " (REHEARSAL: all ranks on one device, collectives through the in-process loopback)" : "");
   for (int r = 0; r < n; ++r) printf("%s%llu", r ? ", " : "", results[size_t(r)].counters[0]);
   printf("]}\n");
   return failed ? 8 : 0;

@@ -84,15 +84,16 @@ typedef struct d2pc_config {
   int32_t border;         /* ROI inset on all four sides; cpp:70,72 => 40     */
   int32_t mode;           /* d2pc_mode                                        */
   float min_disparity;    /* COMPACT only: also drop d <= this; -inf = off    */
-  int32_t compact_algo;   /* 0 = library default: chunked two-pass (4) for
-                             launches of >= 4 frames and >= ~25k tiles; one
-                             launch of resident blocks (3) for camera-size
-                             launches that are not being captured; two-pass
-                             (1) else.  1 = two-pass count/scan/scatter;
+  int32_t compact_algo;   /* 0 = library default: single pass (2) for launches
+                             of >= 4 frames and >= ~25k tiles; one launch of
+                             resident blocks (3) for launches of up to two 4K
+                             frames that are not being captured; two-pass (1)
+                             else.  1 = two-pass count/scan/scatter;
                              2 = single-pass counted hand-off; 3 = resident
                              blocks (falls back where impossible); 4 = chunked
-                             two-pass of one-shot blocks.  Same bytes out
-                             whatever the value. */
+                             two-pass of one-shot blocks (measured slower than
+                             2: DESIGN.md section 7).  Same bytes out whatever
+                             the value. */
   int32_t reserved[4];
 } d2pc_config;
 

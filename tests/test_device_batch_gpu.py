@@ -419,8 +419,81 @@ def test_resident_one_launch_compaction_over_many_relaunches_and_sizes():
                     assert np.array_equal(idx, want[f][1]), f"{w}x{h} rep {rep} frame {f}"
                     assert_points_close(pts, want[f][0], max_ulp=1, what=f"{w}x{h} rep {rep} frame {f}")
             st = ctx.compact_stats()
-            tiles = n * -(-d2pc.roi_points(w, h, 40) // 2048)
-            assert st["timeouts"] == 0 and st["launches"] == (8 if tiles <= 1024 else 0), (w, h, st)
+            # resident in ordinary 2048-pixel tiles, or -- one or two 4K frames -- in blocks of 32 / 64 pixels per thread
+            fits = any(n * -(-d2pc.roi_points(w, h, 40) // (256 * r)) <= 1024 for r in (8, 32, 64))
+            assert st["timeouts"] == 0 and st["launches"] == (8 if fits else 0), (w, h, st)
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_c4_4k_compact_frames_take_one_launch(n):
+    """A camera delivers frames one at a time: one (or two) 4K frames in COMPACT mode used to take two launches and two
+    reads of the input (3,819 tiles > the 1,024 resident blocks).  k_compact_resident_lean: 8,192 / 16,384 pixels per
+    block, disparities in registers between count and scatter -- ONE launch, default routing, indices and points
+    against the oracle."""
+    q = d2pc.make_q()
+    frames = [synth_disparity(4, 30 + f, 3840, 2160, ["holes", "blocky"][f % 2]) for f in range(n)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        b = _batch(ctx, frames, want_index=True)
+        ctx.compact_stats_reset()
+        for _ in range(3):
+            b.points.fill_(0)
+            b.launch()
+        res = b.results()
+        ctx.check_async_error()
+        st = ctx.compact_stats()
+    assert st["launches"] == 3 and st["timeouts"] == 0 and st["tiles"] == 3 * n * -(-d2pc.roi_points(3840, 2160, 40) // (256 * 32 * n))
+    for f, (pts, idx) in enumerate(res):
+        wp, wi = oracle.reproject_compact(frames[f], q, border=40)
+        assert len(pts) == len(wp), f"frame {f} count"
+        assert np.array_equal(idx, wi), f"frame {f} indices"
+        assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"4K compact frame {f}")
+
+
+@pytest.mark.parametrize("rpxt", [32, 64])
+@pytest.mark.parametrize("case", ["f32", "f32_odd", "u8", "u16", "general", "sliver", "cv24", "min_disparity"])
+def test_resident_lean_blocks_on_ragged_frames(rpxt, case):
+    """The register-resident blocks forced (tuning resident_pxt) onto small ragged frames: last blocks reaching past the
+    ROI, rows wrapping inside a wave's run, 8- and 16-bit input, a general Q (the real arithmetic counts), a Q whose W
+    lands in the sliver (ditto, per wave), OpenCV 2.4's form, a disparity floor."""
+    w, h, border, n = (1001, 333, 3, 3) if case == "f32_odd" else (1000, 700, 7, 2)
+    q = d2pc.make_q(cx=w / 2 - 0.3, cy=h / 2 + 0.4, nx=w, ny=h)
+    scale, form, dmin = 1.0, oracle.FORM_CV24, -np.inf
+    rng = np.random.default_rng(rpxt + len(case))
+    if case in ("u8", "u16"):
+        hi, dt = (256, np.uint8) if case == "u8" else (65536, np.uint16)
+        frames = [rng.integers(0, hi, size=(h, w)).astype(dt) for _ in range(n)]
+        for fr in frames:
+            fr[rng.random((h, w)) < 0.3] = 0
+        scale = 0.125 if case == "u8" else 1.0 / 64
+    else:
+        frames = [synth_disparity(3, 50 + f, w, h, ["holes", "blocky", "uniform"][f % 3]) for f in range(n)]
+        frames[0][h // 2, 5:11] = [np.nan, np.inf, -np.inf, -1.0, 3.4028235e38, 1e-45]
+    if case == "general":
+        q = rng.uniform(-1, 1, 16)
+        q[12:16] = [2e-4, 1e-4, 0.03, 0.7]
+        form = oracle.FORM_CV4
+    if case == "sliver":
+        q[14] = 1e-36
+    if case == "min_disparity":
+        dmin = 40.0
+    ulp = 0 if case in ("general", "cv24") else 1
+    with d2pc.Context(q=q, border=border, mode=d2pc.MODE_COMPACT, compact_algo=3, min_disparity=dmin) as ctx:
+        ctx.set_tuning("resident_pxt", rpxt)
+        if case == "cv24":
+            ctx.set_reproject_form(d2pc.FORM_CV24)
+        b = _batch(ctx, frames, want_index=True)
+        ctx.compact_stats_reset()
+        for _ in range(2):
+            b.points.fill_(0)
+            b.launch(scale=scale)
+        res = b.results()
+        ctx.check_async_error()
+        assert ctx.compact_stats()["launches"] == 2
+    for f, (pts, idx) in enumerate(res):
+        wp, wi = oracle.reproject_compact(frames[f], q, border=border, scale=scale, form=form, min_disparity=dmin)
+        assert len(pts) == len(wp), f"frame {f} count"
+        assert np.array_equal(idx, wi), f"frame {f}"
+        assert_points_close(pts, wp, max_ulp=ulp, rel=1e-5, what=f"frame {f}")
 
 
 def test_resident_compaction_alternates_with_the_other_forms_on_one_state_buffer():

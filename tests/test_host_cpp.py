@@ -347,6 +347,69 @@ def test_multi_gpu_mode_with_one_rank(replay, tmp_path, mode, how):
     assert rec["pixels"] == 7 * 752 * 480 and rec["points"] == 7 * len(want)
 
 
+def test_share_device_rehearsal_argument_handling_also_under_tsan(replay):
+    """`--share-device` (N ranks on one device, collectives through the in-process loopback): its command-line rules,
+    with the ordinary binary and with the ThreadSanitizer build (`make -C host tsan`), which must stay silent."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "host"), "tsan"], check=True, capture_output=True)
+    tsan = os.path.join(ROOT, "host", "d2pc_replay_tsan")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    import disparity_to_point_cloud_amd as d2pc
+    for exe in (replay, tsan):
+        for args, needle in ((("--gpus", "17", "--share-device"), "at most 16"),
+                             (("--device", "0", "--share-device"), "one rank"),
+                             (("--gpus", "2", "--devices", "0,1", "--share-device"), "ONE device"),
+                             (("--share-device",), "--gpus N missing"),
+                             (("--gpus", "2", "--share-device", "--depth", "0"), "1..8")):
+            p = subprocess.run([exe, *args], capture_output=True, text=True, timeout=60, env=env)
+            assert p.returncode == 2 and needle in p.stderr and "ThreadSanitizer" not in p.stderr, (exe, args, p.returncode, p.stderr)
+        if d2pc.device_count() == 0:
+            p = subprocess.run([exe, "--gpus", "3", "--share-device"], capture_output=True, text=True, timeout=60, env=env)
+            assert p.returncode == 5 and "no CPU path" in p.stderr and "ThreadSanitizer" not in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,mode", [(2, "parity"), (4, "compact"), (3, "parity")])
+def test_multi_gpu_mode_rehearsed_with_n_ranks_on_one_device(replay, tmp_path, n, mode):
+    """Round 3's verdict: the native harness had only ever run with ONE rank.  `--gpus N --share-device`: N rank threads,
+    N contexts, N frame queues concurrently on device 0; the calibration travels rank 0 -> every rank's device buffer
+    (poisoned beforehand) through the loopback's broadcast and every rank configures itself from what it RECEIVED;
+    counters are all-reduced.  Every rank's blob is bitwise rank 0's, every rank's last cloud matches the oracle, the
+    counters add up.  (Thread-per-GPU concurrency: src/disparity_to_point_cloud_node.cpp:46-52, hpp:77-78.)"""
+    import json
+
+    import disparity_to_point_cloud_amd as d2pc
+
+    rng = np.random.default_rng(n)
+    img = rng.integers(0, 256, size=(480, 752)).astype(np.uint8)
+    img[rng.random(img.shape) < 0.3] = 0
+    src = tmp_path / "frame.raw"
+    src.write_bytes(img.tobytes())
+    prefix = tmp_path / "multi"
+    frames = 11
+    args = [replay, "--gpus", str(n), "--share-device", "--frames", str(frames), "--in", str(src), "--out", str(prefix),
+            "--depth", "2", "fx_=690.25", "cx_=371.5"]
+    if mode == "compact":
+        args.append("--compact")
+    p = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    q = d2pc.make_q_flavour(fx=690.25, cx=371.5)
+    want_blob = d2pc.calib_pack(q, 40, d2pc.MODE_COMPACT if mode == "compact" else d2pc.MODE_PARITY)
+    med = oracle.median_u8(img, 11)
+    if mode == "parity":
+        want = oracle.reproject(med, q, border=40, scale=0.125)
+    else:
+        want, _ = oracle.reproject_compact(med, q, border=40, scale=0.125)
+    for r in range(n):
+        assert (tmp_path / f"multi.rank{r}.blob").read_bytes() == want_blob, f"rank {r} received another calibration"
+        pts = np.frombuffer((tmp_path / f"multi.rank{r}.cloud").read_bytes(), dtype=np.float32).reshape(-1, 4)
+        assert_points_close(pts, want, max_ulp=1, rel=1e-5, what=f"rehearsal, rank {r} of {n}")
+    assert rec["rehearsal_shared_device"] is True and rec["n_gpus"] == n and rec["devices"] == [0] * n
+    assert rec["per_rank_frames"] == [frames] * n and rec["frames"] == n * frames
+    assert rec["pixels"] == n * frames * 752 * 480 and rec["points"] == n * frames * len(want)
+    assert "REHEARSAL" in rec["what"]
+
+
 @pytest.mark.gpu
 def test_multi_gpu_mode_refuses_a_second_device_on_a_one_gpu_box(replay):
     import disparity_to_point_cloud_amd as d2pc

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Counter passes for ONE workload of tools/probe.py: separate rocprofv3 --pmc runs (the blocks have few
 # slots per pass; FETCH_SIZE and WRITE_SIZE cannot share one), kernel-trace only -- never combined with
-# --sys-trace / hip / hsa tracing.  Usage: [PASSES="sq1 sq4"] [TUNE="--tune median_algo=1"] tools/pmc_passes.sh <workload> <outdir-tag> [launches]
+# --sys-trace / hip / hsa tracing.  Usage: [ALGO=4] [PASSES="sq1 sq4"] [TUNE="--tune median_algo=1"] tools/pmc_passes.sh <workload> <outdir-tag> [launches]
 set -e
 WL=$1; TAG=$2; N=${3:-6}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -10,7 +10,7 @@ mkdir -p $OUT
 run() {  # name, counters...
   local name=$1; shift
   if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $name "; then return; fi   # PASSES="sq1 sq2": a subset
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o run -- python3 tools/probe.py --workload $WL --launches $N $TUNE > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o run -- python3 tools/probe.py --workload $WL --launches $N $TUNE ${ALGO:+--algo $ALGO} > $OUT/$name.log 2>&1
   echo "pass $name done"
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
