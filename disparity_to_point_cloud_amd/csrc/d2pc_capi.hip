@@ -195,13 +195,17 @@ int grow(d2pc_ctx *ctx, void **p, size_t *cap, size_t need) {
 // PARITY tile shape.  Default (round 3): ONE-SHOT blocks of 512 pixels, two per thread (k_reproject_pack_small) -- against
 // the tile-walking kernel with 8 pixels per thread, interleaved on one device: 16 x 4K 427 -> 394 us (border 40), 457 -> 407 us
 // (border 0); one 4K frame 24.9 -> 23.0 us; 64 x 752x480 51.2 -> 49.6 us; never slower (profiles/r03_sweep_parity_small.txt).
-// One pixel per thread is as good for launches that fit the caches and 15 % worse for the big batch.
+// One pixel per thread is as good for fp32 launches that fit the caches and 15 % worse for the big fp32 batch.
+// 8- and 16-bit input -- what the reference's callback really holds (cpp:60-61) -- swept in round 4
+// (profiles/r04_sweep_parity_small_u8.txt): two pixels per thread up to ~8 x 4K (2 x 4K: 38.1 against 45.5 us), ONE pixel per
+// thread beyond (16 x 4K: u8 281.6 against 313.0 us, u16 298.2 against 325.7; equal at 8 x 4K).
 // pxt_parity 4 / 8 / 16 select the tile-walking kernel (1024-pixel tiles were its best for launches of <= 32 Mpixel).
-int parity_pxt(const d2pc_ctx *ctx, int width, int height, int n_frames) {
-  (void)width;
-  (void)height;
-  (void)n_frames;
-  return ctx->pxt_parity ? ctx->pxt_parity : 2;
+int parity_pxt(const d2pc_ctx *ctx, int width, int height, int n_frames, int dtype = D2PC_DTYPE_F32) {
+  if (ctx->pxt_parity) return ctx->pxt_parity;
+  if (dtype == D2PC_DTYPE_F32) return 2;
+  const long long b = ctx->cfg.border, rw = (long long)width - 2 * b, rh = (long long)height - 2 * b;
+  const long long px = rw > 0 && rh > 0 ? rw * rh * (long long)n_frames : 0;
+  return px >= 96000000ll ? 1 : 2;
 }
 
 // Validates the frame description and fills the launch geometry.
@@ -1113,7 +1117,7 @@ int d2pc_process_device(d2pc_ctx *ctx, const void *d_disp, int dtype, float scal
   const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
   Geom g;
   int st = make_geom(ctx, dtype, scale, width, height, row_stride, in_frame_stride, n_frames, out_frame_stride,
-                     compact ? ctx->pxt_compact : parity_pxt(ctx, width, height, n_frames), &g);
+                     compact ? ctx->pxt_compact : parity_pxt(ctx, width, height, n_frames, dtype), &g);
   if (st != D2PC_OK) return st;
   if (reinterpret_cast<uintptr_t>(d_disp) % elem_size(dtype) != 0)
     return fail(ctx, D2PC_ERR_INVALID_ARG, "d_disp is not aligned to its sample type");
@@ -1518,7 +1522,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(ctx, D2PC_ERR_NO_DEVICE, "cannot select device %d", ctx->device);
   const bool compact = ctx->cfg.mode == D2PC_MODE_COMPACT;
-  const int pxt = compact ? ctx->pxt_compact : parity_pxt(ctx, width, height, n_frames);
+  const int pxt = compact ? ctx->pxt_compact : parity_pxt(ctx, width, height, n_frames, D2PC_DTYPE_U8);  // (the reprojection sees 8-bit frames)
   Geom gin;  // validates the caller's layout
   int st = make_geom(ctx, bridge16 ? int(D2PC_DTYPE_U16) : int(D2PC_DTYPE_U8), scale, width, height, row_stride,
                      frame_stride, n_frames, out_frame_stride, pxt, &gin);

@@ -2492,7 +2492,7 @@ __global__ __launch_bounds__(256) void k_state_clear(uint4 *__restrict__ p, uint
 }
 
 #if D2PC_CLEAR_WITH_MEMSET
-__global__ __launch_bounds__(256) void k_state_verify(const uint4 *__restrict__ p, uint32_t n16, CompactStats *stats) {
+__global__ __launch_bounds__(256) void k_state_verify(uint4 *__restrict__ p, uint32_t n16, CompactStats *stats) {
   using gu32 = __attribute__((address_space(1))) const uint32_t;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i == 0) atomicAdd(&stats->dbg[1], 1ull);
@@ -2502,6 +2502,10 @@ __global__ __launch_bounds__(256) void k_state_verify(const uint4 *__restrict__ 
     for (int k = 0; k < 4; ++k) any |= __hip_atomic_load((gu32 *)(w + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (any) atomicAdd(&stats->dbg[0], 1ull);
   }
+  // the memset wiped the header's pointer to the context's counters, which k_state_clear would have written: without it
+  // the single pass behind this kernel adds its counters through a null pointer (round 4: a memory access fault at
+  // 0x1000 on the first launch of this experiment build).  Written by the thread that looked at piece 0, after it looked.
+  if (i == 0) reinterpret_cast<StateHeader *>(p)->stats = stats;
 }
 #endif
 
@@ -2529,7 +2533,7 @@ static hipError_t launch_compact_t(const LaunchArgs &a) {
     if (hipError_t e = hipMemsetAsync(a.state, 0, a.state_bytes, a.stream); e != hipSuccess) return e;
     // ... followed by a kernel that counts the 16-byte pieces of the state that are NOT zero when it runs
     // (stats->pad[0]) and the launches it looked at (pad[1]): d2pc_debug_read_stats
-    hipLaunchKernelGGL(k_state_verify, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<const uint4 *>(a.state), n16,
+    hipLaunchKernelGGL(k_state_verify, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(a.state), n16,
                        static_cast<CompactStats *>(a.stats));
 #else
     hipLaunchKernelGGL(k_state_clear, dim3((n16 + 255) / 256), dim3(256), 0, a.stream, static_cast<uint4 *>(a.state), n16,

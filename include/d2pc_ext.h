@@ -38,10 +38,13 @@ int d2pc_release_graph_buffers(d2pc_ctx *ctx);
 
 /* ---- the kernels' own counters ------------------------------------------------------------------------------ */
 /*
- * Counters of the single-pass compaction (compact_algo 2), summed over the context's launches since creation or
- * d2pc_compact_stats_reset -- the production build's view of the in-launch hand-off (the reference has only
- * printf breadcrumbs, cpp:47-91).  Call after synchronising the streams that carried the launches.
- *   launches           single-pass launches
+ * Counters of the in-launch hand-offs, summed over the context's launches since creation or d2pc_compact_stats_reset:
+ * EVERY kernel that hands counts over inside a launch adds to them -- the single pass (compact_algo 2), the resident
+ * one-launch forms (compact_algo 3: k_compact_resident, k_compact_resident_lean) and the tile-fused callback kernels of
+ * d2pc_process_mono_device (advisor, round 3: the header used to name the single pass only).  The production build's
+ * view of the hand-offs (the reference has only printf breadcrumbs, cpp:47-91).  Call after synchronising the streams
+ * that carried the launches.
+ *   launches           launches of those kernels
  *   tiles              tiles they served (each takes one ticket and needs the counts of its predecessors)
  *   failed_polls       looks at a predecessor's count that found it unpublished; failed_polls / tiles is the
  *                      hand-off's health: ~0.1 on an idle device, more when predecessors are delayed

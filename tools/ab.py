@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--small", type=int, default=None, help="tuning parity_small (1: one-shot blocks also for pxt 4)")
     ap.add_argument("--forms", default="0", help="tuning reproject_form (0 per Q kind, 24 / 4: one OpenCV generation bit for bit)")
     ap.add_argument("--tunes", default="", help="alternatives separated by ';', each a comma-separated list of d2pc_set_tuning key=value (e.g. 'chunk_mb=96;chunk_mb=48,chunk_first_frames=1')")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "u8", "u16"], help="input sample type (u8 / u16: the fused cpp:61 decode, scale 1/8 and 1/64)")
     ap.add_argument("--w", type=int, default=3840)
     ap.add_argument("--h", type=int, default=2160)
     a = ap.parse_args()
@@ -45,12 +46,17 @@ def main():
     import disparity_to_point_cloud_amd as d2pc
     g = torch.Generator(device="cuda").manual_seed(1)
     disp = torch.rand((a.frames, a.h, a.w), generator=g, device="cuda") * 127.5 + 0.5
+    dcode, dscale, esize = {"f32": (0, 1.0, 4), "u8": (1, 0.125, 1), "u16": (2, 1.0 / 64, 2)}[a.dtype]
     if a.holes > 0 and a.blocky:
         m = (torch.rand((a.frames, (a.h + 63) // 64, (a.w + 63) // 64), generator=g, device="cuda") >= a.holes).float()
         m = m.repeat_interleave(64, dim=1).repeat_interleave(64, dim=2)[:, :a.h, :a.w]
         disp.mul_(m)
     elif a.holes > 0:
         disp.mul_((torch.rand(disp.shape, generator=g, device="cuda") >= a.holes).float())
+    if a.dtype == "u8":
+        disp = (disp * 2).to(torch.uint8)          # 0 stays 0 (a hole), 1..255
+    elif a.dtype == "u16":
+        disp = (disp * 64).to(torch.int32).to(torch.uint16)
     cands = []
     # ONE set of buffers for every candidate: kernel time depends on which
     # physical pages a buffer got (+-6 % between allocations of one process)
@@ -70,7 +76,7 @@ def main():
             self.out_ptr = pool.data_ptr() + 16 * ooff
             ctx.reserve(W, H, F)
         def launch(self):
-            self.ctx.process_device(disp.data_ptr(), 0, 1.0, W, H, W * 4, W * H * 4, F, self.out_ptr,
+            self.ctx.process_device(disp.data_ptr(), dcode, dscale, W, H, W * esize, W * H * esize, F, self.out_ptr,
                                     index.data_ptr() if index is not None else None, self.stride, counts.data_ptr(), stream)
 
     for lib in a.libs.split(","):
@@ -94,7 +100,7 @@ def main():
             b.launch(); torch.cuda.synchronize()
             npts = int(counts.sum().item())
             roi_n = capi.roi_points(W, H, int(border))
-            alg = 4 * F * roi_n + (20 if a.idx else 16) * npts
+            alg = esize * F * roi_n + (20 if a.idx else 16) * npts
             cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo} oalign={oal} ooff={oof} form={form} {tune}", b, alg, []))
     for r in range(a.rounds):
         for label, b, alg, ts in cands:

@@ -24,6 +24,46 @@ hip = ctypes.CDLL("libamdhip64.so")
 vp = ctypes.c_void_p
 
 
+class MemsetParams(ctypes.Structure):   # hipMemsetParams (hip/driver_types.h)
+    _fields_ = [("dst", ctypes.c_void_p), ("elementSize", ctypes.c_uint), ("height", ctypes.c_size_t),
+                ("pitch", ctypes.c_size_t), ("value", ctypes.c_uint), ("width", ctypes.c_size_t)]
+
+
+def memset_nodes(graph):
+    """[(dst, bytes, value)] of the graph's memset nodes as the runtime recorded them (hipGraphMemsetNodeGetParams)."""
+    n = ctypes.c_size_t(0)
+    ck(hip.hipGraphGetNodes(graph, None, ctypes.byref(n)), "hipGraphGetNodes")
+    nodes = (vp * n.value)()
+    ck(hip.hipGraphGetNodes(graph, nodes, ctypes.byref(n)), "hipGraphGetNodes")
+    out = []
+    for nd in nodes:
+        t = ctypes.c_int()
+        ck(hip.hipGraphNodeGetType(vp(nd), ctypes.byref(t)), "hipGraphNodeGetType")
+        if t.value == 2:   # hipGraphNodeTypeMemset
+            p = MemsetParams()
+            ck(hip.hipGraphMemsetNodeGetParams(vp(nd), ctypes.byref(p)), "hipGraphMemsetNodeGetParams")
+            out.append((p.dst, p.width * p.elementSize * max(p.height, 1), p.value))
+    return out, n.value
+
+
+class CaptureStderr:
+    """fd 2 into a file for the duration (the experiment build prints `d2pc: hipMemsetAsync(ptr, 0, bytes)` under D2PC_TRACE_MEMSET)."""
+    def __enter__(self):
+        import tempfile
+        sys.stderr.flush()
+        self.f = tempfile.TemporaryFile()
+        self.saved = os.dup(2)
+        os.dup2(self.f.fileno(), 2)
+        return self
+
+    def __exit__(self, *a):
+        os.dup2(self.saved, 2)
+        os.close(self.saved)
+        self.f.seek(0)
+        self.text = self.f.read().decode(errors="replace")
+        self.f.close()
+
+
 def ck(e, what):
     if e != 0:
         raise RuntimeError(f"{what}: hip error {e}")
@@ -70,9 +110,18 @@ for capture in ("torch", "torch_side", "hip", "hip_null"):
                 ck(hip.hipStreamCreateWithFlags(ctypes.byref(raw), 1), "hipStreamCreateWithFlags")  # non-blocking
                 stream = torch.cuda.ExternalStream(raw.value)
                 graph, gexec = vp(), vp()
-                ck(hip.hipStreamBeginCapture(raw, 0), "hipStreamBeginCapture")  # hipStreamCaptureModeGlobal
-                b.launch(stream=stream)
-                ck(hip.hipStreamEndCapture(raw, ctypes.byref(graph)), "hipStreamEndCapture")
+                os.environ["D2PC_TRACE_MEMSET"] = "1"
+                with CaptureStderr() as cap:
+                    ck(hip.hipStreamBeginCapture(raw, 0), "hipStreamBeginCapture")  # hipStreamCaptureModeGlobal
+                    b.launch(stream=stream)
+                    ck(hip.hipStreamEndCapture(raw, ctypes.byref(graph)), "hipStreamEndCapture")
+                os.environ.pop("D2PC_TRACE_MEMSET")
+                import re
+                lib_calls = [(int(m.group(1), 16), int(m.group(2))) for m in re.finditer(r"hipMemsetAsync\((0x[0-9a-f]+), 0, (\d+)\)", cap.text)]
+                recorded, n_nodes = memset_nodes(graph)
+                node_report = (f"library asked for {[(hex(p), n_) for p, n_ in lib_calls]}; graph of {n_nodes} nodes holds memset "
+                               f"{[(hex(p or 0), n_, v) for p, n_, v in recorded]}: "
+                               + ("MATCH" if [(p, n_) for p, n_, _ in recorded] == lib_calls and all(v == 0 for *_, v in recorded) else "DIFFER"))
                 ck(hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, ctypes.c_size_t(0)), "hipGraphInstantiate")
 
                 if capture == "hip_null":   # captured on `raw`, launched on the legacy default stream
@@ -96,4 +145,8 @@ for capture in ("torch", "torch_side", "hip", "hip_null"):
             if not host_reads:
                 ok = np.array_equal(b.counts.cpu().numpy(), want)
                 results.append(f"after 4 replays without a host read: counts {'ok' if ok else 'WRONG'}, {flag(ctx)} {dirty(ctx)}")
+            if capture in ("hip", "hip_null"):
+                again, _ = memset_nodes(graph)   # ... and once more after the replays
+                node_report += "; after the replays " + ("unchanged" if again == recorded else f"CHANGED to {again}")
+                results.append(node_report)
             print(f"capture via {capture:10s}, host reads between replays {host_reads}: " + "; ".join(results), flush=True)
