@@ -188,7 +188,11 @@ int d2pc_set_mode(d2pc_ctx *ctx, int mode);
  *                      parallel only for a Q whose column steps are exact
  *                      (q00 = 1, q01 = q10 = q20 = q30 = +0 -- what
  *                      stereoRectify and d2pc_make_q* produce); any other Q
- *                      makes the next call return D2PC_ERR_INVALID_ARG
+ *                      makes the next call return D2PC_ERR_INVALID_ARG.  The
+ *                      running sum rounds once per binade it crosses inside a
+ *                      row; the library holds 18 such segments (a principal
+ *                      point of any size on rows of up to 65,536 columns) and
+ *                      returns D2PC_ERR_BAD_SIZE beyond
  *   D2PC_FORM_CV4      OpenCV 3/4's form bit for bit for every Q (Matx product
  *                      left to right, numerators cast to float, times 1./W)
  * For cv::stereoRectify's Q the exact forms have kernels of their own and cost

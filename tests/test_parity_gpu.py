@@ -357,6 +357,29 @@ def test_reproject_form_selects_one_opencv_generation_bit_for_bit(w, h, border, 
                 _same_bits(gp, wp, f"compact (algo {algo}) form {form} general={general} {w}x{h}")
 
 
+@pytest.mark.parametrize("q03", [-0.1, -0.7, -1e-9, 0.3, -2047.9])
+def test_reproject_form_24_with_a_principal_point_that_crosses_many_binades(q03):
+    """Advisor, round 3: OpenCV 2.4's running column sum qx += q00 rounds once per binade it crosses; a SMALL non-dyadic
+    principal point crosses one per doubling of the column (q03 = -0.1: 13 over 4100 columns), more than the 7 segments the
+    host's table used to hold, and the table was replayed over 4096 columns whatever the width -- D2PC_ERR_BAD_SIZE for a
+    valid calibration.  Now 18 segments, replayed over the frame's own width: bit for bit on both routes, wide and narrow."""
+    for w, h in ((4100, 6), (70, 9)):
+        q = d2pc.make_q(nx=w, ny=h)
+        q[3] = q03
+        disp = synth_disparity(3, w, w, h, "holes")
+        want = oracle.reproject(disp, q, border=0, form=oracle.FORM_CV24)
+        wp, wi = oracle.reproject_compact(disp, q, border=0, form=oracle.FORM_CV24)
+        for general in (0, 1):
+            with ctx_for(q, border=0) as ctx:
+                ctx.set_reproject_form(d2pc.FORM_CV24)
+                ctx.set_test_hook("force_general_q", general)
+                _same_bits(ctx.process(disp), want, f"q03={q03} {w}x{h} general={general}")
+                ctx.set_mode(d2pc.MODE_COMPACT)
+                gp, gi = ctx.process(disp, want_index=True)
+            assert np.array_equal(gi, wi)
+            _same_bits(gp, wp, f"compact q03={q03} {w}x{h} general={general}")
+
+
 def test_reproject_form_24_u8_and_scale(q_default):
     """The node's own input (uint8 disparities times 1/8, cpp:61) through OpenCV 2.4's form, bit for bit."""
     rng = np.random.default_rng(24)
