@@ -87,6 +87,8 @@ struct d2pc_ctx {
   int big_batch_algo = 2;          // COMPACT launches of >= 4 frames and >= 24,576 tiles: 2 = single pass (default: faster), 4 = chunked two-pass of one-shot blocks
   int chunk_mb = 96;               // algo 4: input bytes per chunk (MiB); the chunk must stay in the 256 MiB Infinity Cache for one launch
   int chunk_first_frames = 0;      // algo 4: frames of the first chunk (0 = an eighth of a chunk)
+  int resident_stagger_pct = -1;   // algo 3, register-resident form: scale of the ramped start in % (0 = every block loads at once;
+                                   // -1 = choose: 50 for one frame that fills the device, else 0)
   int resident_unbounded = 0;      // algo 3, experiment: admit launches of more blocks than are resident at once (see enqueue)
   int resident_pxt = 0;            // algo 3: pixels per thread of its blocks (0 = choose: the ordinary tile if the launch fits, else 32, else 64)
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
@@ -573,6 +575,15 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   if (a.compact_algo == 3 && resident_pxt != int(g.pxt)) {
     Geom gr = g;
     retile(&gr, resident_pxt);
+    // the ramped start of k_compact_resident_lean: a block's input bytes at ~6 TB/s and ~2.4 GHz, in 64-cycle sleeps x 1024
+    // (R = 32, fp32: 32 KiB per block = 13 cycles = 0.2 sleeps per block index); tuning "resident_stagger_pct" scales it
+    // Measured (profiles/r04_ab_stagger.txt): half that ramp is worth 1.4-1.8 us on ONE 4K frame (31.2 -> 29.8 us with 30 % holes
+    // + indices, 32.2 -> 30.4 all valid) and nothing or less on two frames and on smaller ones, whose blocks do not fill the
+    // device: it is applied to single frames of >= 7/8 of the resident capacity only.
+    const double block_bytes = double(kBlock) * resident_pxt * double(elem_size(dtype));
+    const bool ramp = ctx->resident_stagger_pct >= 0 ? true : (gr.n_frames == 1 && dtype == D2PC_DTYPE_F32 && gr.total_tiles * 8u >= resident_cap * 7u);
+    const int pct = ctx->resident_stagger_pct >= 0 ? ctx->resident_stagger_pct : 50;
+    gr.stagger = ramp ? uint32_t(block_bytes / 6.0e12 * 2.4e9 / 64.0 * 1024.0 * pct / 100.0) : 0u;
     a.geom = gr;
     a.pxt = resident_pxt;
   }
@@ -1018,6 +1029,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "big_batch_algo") && (value == 2 || value == 4)) ctx->big_batch_algo = value;
+  else if (!strcmp(key, "resident_stagger_pct") && value >= -1 && value <= 1000) ctx->resident_stagger_pct = value;
   else if (!strcmp(key, "resident_unbounded") && (value == 0 || value == 1)) ctx->resident_unbounded = value;
   else if (!strcmp(key, "resident_pxt") && (value == 0 || value == 32 || value == 64 || tile_shape_supported(value))) ctx->resident_pxt = value;
   else if (!strcmp(key, "chunk_mb") && value >= 1 && value <= 4096) ctx->chunk_mb = value;

@@ -57,6 +57,7 @@ struct Geom {
   float min_disparity;                // compact predicate: drop d <= this
   uint32_t spin_ticks;                // single pass: hand-off wait budget in s_memrealtime ticks (100 MHz)
   uint32_t pxt;                       // ROI pixels per thread the tile counts above were formed with (host side)
+  uint32_t stagger;                   // k_compact_resident_lean: block t starts its loads (t * stagger) >> 10 sleeps of 64 cycles late
 };
 
 // Binades a 2.4-style running sum may cross inside one image row: one per doubling of the column for a small principal

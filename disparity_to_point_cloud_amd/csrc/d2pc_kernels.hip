@@ -1143,6 +1143,12 @@ __global__ __launch_bounds__(kBlock) void k_compact_resident_lean(const uint8_t 
   const FrameState fs(state, g, f);
   const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
   const uint32_t i0 = lt * uint32_t(kBlock * R) + wave * uint32_t(64 * R) + lane;  // pixel k of the lane: i0 + 64 k
+  // A RAMPED start: every block of the launch is resident and would ask for its pixels at once; the whole launch's input then
+  // arrives together (~5.5 us for a 4K frame), everybody counts, publishes and looks back together (~3 us) and only then does the
+  // first store leave -- read phase, bubble, write phase.  Block t waits t x (its bytes / the read rate) instead, so the data
+  // arrive in block order at the rate memory delivers them anyway, the first blocks are storing while the last ones still load,
+  // and the bubble is hidden (one 4K frame: profiles/r04_ab_resident.txt).
+  for (uint32_t n = (t * g.stagger) >> 10; n > 0; --n) __builtin_amdgcn_s_sleep(1);
   float d[R];
   {
     // coordinates stepped from slot to slot (rows wrap inside the run): one division per thread
