@@ -34,8 +34,8 @@ struct StateBuf {
   int algo = 0;                  // algorithm of that launch: 2 = single pass (its header holds the timeout flag),
                                  // 3 = resident blocks (the flag holds the launch's epoch)
   uint32_t epoch = 0;            // algo 3: that launch's epoch
-  uint64_t chunk_sig = 0;        // algo 4: frames and frame stride of that launch (its frame counters sit where the next
-                                 // launch of the same shape expects them, and read zero)
+  uint64_t chunk_sig = 0;        // algo 4: tiles per frame and frames of that launch (its frame counters and "empty" marks sit
+                                 // where the next launch of the same shape expects them)
   bool captured = false;         // a stream capture baked the pointer into a graph: never freed, moved or shared
                                  // until d2pc_release_graph_buffers
   unsigned long long capture_id = 0;
@@ -645,7 +645,9 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   if (st != D2PC_OK) return st;
   a.state = sb->p;
   if (a.compact_algo == 4) {
-    const uint64_t sig = (uint64_t(a.geom.frame_state_stride) << 32) | a.geom.n_frames;
+    // (tiles per frame, frames): they fix the groups, the padded words and the stride -- two shapes may share a 256-byte-rounded
+    // stride and still keep their group totals in different words, and a stale word that is not "empty" would be taken for a total
+    const uint64_t sig = (uint64_t(a.geom.tiles_per_frame) << 32) | a.geom.n_frames;
     a.chunk_clear = sb->algo != 4 || sb->chunk_sig != sig;
     sb->chunk_sig = sig;
   }
@@ -1641,7 +1643,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
           // Residency.  Both forms of the kernel hand counts over between the tiles of a BAND, and a frame's blocks are
           // dispatched round-robin over the launch's frames (frame = blockIdx % n_frames): a frame needs tiles_x of its
           // own blocks resident at once, or no frame ever finishes band 0 (advisor, round 3: from ~385 frames of 752x480
-          // or ~55 frames of 4K every wave span out its 4-s budget).  A call with more frames than that is cut into
+          // or ~55 frames of 4K every wave spun out its 4-s budget).  A call with more frames than that is cut into
           // sub-batches of nfc frames with resident / nfc > tiles_x, launched back to back on the same stream (they share
           // the stream's state buffer: a sub-batch's zeroing kernel runs behind the previous sub-batch's last store).
           const uint32_t tiles_x = (g.roi_w + 255u) / 256u, tiles_y = (g.roi_n / g.roi_w + 31u) / 32u, tpf = tiles_x * tiles_y;

@@ -662,7 +662,7 @@ def test_tile_fused_compact_kernel_with_degenerate_scales_and_a_disparity_floor(
 @pytest.mark.parametrize("n,h,w", [(500, 120, 400), (1000, 120, 160)])
 def test_tile_fused_compact_kernel_with_more_frames_than_resident_bands(n, h, w):
     """Advisor, round 3: a frame needs a whole band of its tiles (tiles_x blocks) resident at once, and blocks go round-robin
-    over the launch's frames -- from ~resident / tiles_x frames on, no frame could finish band 0 and every wave span out its
+    over the launch's frames -- from ~resident / tiles_x frames on, no frame could finish band 0 and every wave spun out its
     wait budget.  400x120 (ROI 320x40: 2 tiles per band) x 500 frames is past that point on 256 CUs x 3 blocks; the host
     now cuts such calls into sub-batches.  Both forms of the kernel against the two launches, bitwise; no timeouts."""
     from disparity_to_point_cloud_amd.torch_api import DeviceBatch

@@ -56,6 +56,9 @@ for c in range(cases):
         ctx.set_test_hook("force_general_q", int(fgen))
         if algo == 4:
             ctx.set_tuning("chunk_mb", int(rng.choice([1, 2, 96])))
+        if algo == 3:   # the ordinary resident tile, or the register-resident blocks of 32 / 64 pixels per thread
+            ctx.set_tuning("resident_pxt", int(rng.choice([0, 32, 64])))
+            ctx.set_tuning("resident_stagger_pct", int(rng.choice([-1, 0, 100])))
         b = DeviceBatch(ctx, n, h, w, dtype=tdt, want_index=idx)
         b.disp.copy_(torch.from_numpy(frames.view(np.int16) if dt == "u16" else frames).view(tdt))
         b.launch(scale=scale)
