@@ -31,6 +31,11 @@ struct StateBuf {
   bool bound = false;
   hipEvent_t done = nullptr;     // recorded behind that launch (not while capturing)
   bool pending = false;          // `done` was recorded and has not been seen complete yet
+  bool dirty = false;            // work was enqueued on `stream` since `done` was last recorded: the record is made LAZILY,
+                                 // when another stream asks for the buffer (settle below).  Recording behind every launch put
+                                 // a marker packet between back-to-back COMPACT launches: 5.5 us of idle device per call -- a
+                                 // sixth of a single 4K frame's time (kernel 26.5 us, launch period 32.4; PARITY, which records
+                                 // nothing: 22.2 / 22.2)
   int algo = 0;                  // algorithm of that launch: 2 = single pass (its header holds the timeout flag),
                                  // 3 = resident blocks (the flag holds the launch's epoch)
   uint32_t epoch = 0;            // algo 3: that launch's epoch
@@ -290,7 +295,39 @@ bool capture_info(hipStream_t s, unsigned long long *id) {
   return st != hipStreamCaptureStatusNone;
 }
 
+// Makes b.done cover everything enqueued on b.stream so far.  False if that cannot be done now (the buffer's stream is
+// inside a capture: a record there would become a node of somebody's graph).
+bool settle(StateBuf &b) {
+  if (!b.dirty) return true;
+  if (capture_info(b.stream, nullptr)) return false;
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;  // (another stream of this thread may be capturing: see state_idle)
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  // has the stream drained?  Then nothing of the buffer's is in flight and no event is needed (an event recorded NOW would
+  // read "not ready" for the microseconds its marker takes, and a capture looking for an idle buffer would find none)
+  hipError_t e = hipStreamQuery(b.stream);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    e = b.done ? hipEventRecord(b.done, b.stream) : hipErrorInvalidHandle;
+    if (e == hipSuccess) {
+      (void)hipThreadExchangeStreamCaptureMode(&mode);
+      b.dirty = false;
+      b.pending = true;
+      return true;
+    }
+  }
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  b.dirty = false;
+  if (e != hipSuccess) {
+    // the stream is gone (destroyed by its owner: its work completes regardless): wait for the device instead
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+  }
+  b.pending = false;
+  return true;
+}
+
 bool state_idle(StateBuf &b) {
+  if (!settle(b)) return false;
   if (!b.pending) return true;
   // another stream of this thread may be capturing (that is when a captured launch looks for a free
   // buffer): an event query is "unsafe" under the global/thread-local capture modes and would
@@ -312,8 +349,9 @@ int state_alloc(d2pc_ctx *ctx, const BufPool *pool, StateBuf &b, size_t need, si
   if (pool && need2 < pool->reserve2) need2 = pool->reserve2;
   if (!b.done) D2PC_HIP(ctx, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
   if (b.cap >= need && b.cap2 >= need2) return D2PC_OK;
-  if ((b.p || b.p2) && b.pending) {
-    D2PC_HIP(ctx, hipEventSynchronize(b.done));  // its last launch still reads and writes it
+  if ((b.p || b.p2) && (b.pending || b.dirty)) {
+    if (!settle(b)) return fail(ctx, D2PC_ERR_DEVICE, "a buffer that must grow is in use by a stream that is being captured");
+    if (b.pending) D2PC_HIP(ctx, hipEventSynchronize(b.done));  // its last launch still reads and writes it
     b.pending = false;
   }
   int st = grow(ctx, &b.p, &b.cap, need);
@@ -391,9 +429,10 @@ int acquire_buf(d2pc_ctx *ctx, BufPool &pool, hipStream_t stream, size_t need, s
         if (!b->captured && !pick) pick = b;
     int st = state_alloc(ctx, &pool, *pick, need, need2);  // waits for the buffer's last launch before it frees anything
     if (st != D2PC_OK) return st;
-    if (pick->pending && !(pick->bound && pick->stream == stream)) {
+    if ((pick->pending || pick->dirty) && !(pick->bound && pick->stream == stream)) {
       // taken over from another stream while busy (only when all buffers were busy): order behind it
-      D2PC_HIP(ctx, hipStreamWaitEvent(stream, pick->done, 0));
+      if (!settle(*pick)) return fail(ctx, D2PC_ERR_DEVICE, "every buffer is in use and one belongs to a stream that is being captured");
+      if (pick->pending) D2PC_HIP(ctx, hipStreamWaitEvent(stream, pick->done, 0));
     }
   }
   pick->stream = stream;
@@ -626,7 +665,9 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
       for (PipeSlot &sl : ctx->slots) all.push_back(&sl.st);  // the pipeline slots' own state buffers carry epochs too
       for (StateBuf *b : all)
         if (b->p) {
+          if (!settle(*b)) return fail(ctx, D2PC_ERR_DEVICE, "epoch wrap-around while a stream that uses the context is being captured");
           if (b->pending) D2PC_HIP(ctx, hipEventSynchronize(b->done));
+          b->pending = false;
           D2PC_HIP(ctx, hipMemsetAsync(b->p, 0, b->cap, nullptr));
           D2PC_HIP(ctx, hipStreamSynchronize(nullptr));
         }
@@ -654,10 +695,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   sb->algo = a.compact_algo;
   sb->epoch = a.epoch;
   D2PC_HIP(ctx, launch_compact(a));
-  if (!sb->captured) {  // an event record inside a capture would become a graph node; a captured buffer is never shared
-    D2PC_HIP(ctx, hipEventRecord(sb->done, stream));
-    sb->pending = true;
-  }
+  if (!sb->captured) sb->dirty = true;  // (a captured buffer is never shared; for the others `done` is recorded when somebody asks)
   return D2PC_OK;
 }
 
@@ -1103,6 +1141,7 @@ int d2pc_release_graph_buffers(d2pc_ctx *ctx) {
         b->captured = false;
         b->bound = false;
         b->pending = false;  // the caller has destroyed the graphs: nothing of theirs is in flight
+        b->dirty = false;
         b->algo = 0;
       }
     // back under the cap on eager buffers: the surplus (idle by the above) is freed
@@ -1684,10 +1723,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
             // (the one-tile-per-block form: ns * tiles_x <= resident - ns by the choice of nfc, so every frame has a whole
             // band of blocks resident from the first dispatch round on)
             D2PC_HIP(ctx, launch_callback_bs_compact(as, ms, static_cast<const uint8_t *>(kin) + size_t(s0) * kin_frame, median_ksize));
-            if (!sb->captured) {
-              D2PC_HIP(ctx, hipEventRecord(sb->done, sr));
-              sb->pending = true;
-            }
+            if (!sb->captured) sb->dirty = true;
           }
           continue;
         }
@@ -1723,8 +1759,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
     ctx->cb_overlap_pending = true;
   }
   if (scratch && !scratch->captured) {  // (inside a capture the record would become a graph node; the buffer is the graph's)
-    D2PC_HIP(ctx, hipEventRecord(scratch->done, user));
-    scratch->pending = true;
+    scratch->dirty = true;
   }
   return D2PC_OK;
 }

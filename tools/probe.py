@@ -21,6 +21,9 @@ WORKLOADS = {  # name: (mode, frames, W, H, border, hole fraction, blocky, indic
     "compact_blocky_idx": ("compact", 16, 3840, 2160, 40, 0.3, 1, True, "f32"),
     "compact_1080p_x32":  ("compact", 32, 1920, 1080, 40, 0.3, 0, True, "f32"),
     "compact_1080p_x1":   ("compact", 1, 1920, 1080, 40, 0.3, 0, True, "f32"),
+    "compact_4k_x1":      ("compact", 1, 3840, 2160, 40, 0.3, 0, True, "f32"),
+    "compact_4k_x1_allvalid": ("compact", 1, 3840, 2160, 40, 0.0, 0, False, "f32"),
+    "parity_4k_x1":       ("parity", 1, 3840, 2160, 40, 0.0, 0, False, "f32"),
     "median11_roi":       ("median", 16, 3840, 2160, 40, 0.0, 0, False, "u8"),
     "callback_u8":        ("callback", 16, 3840, 2160, 40, 0.0, 0, False, "u8"),
 }
