@@ -1473,6 +1473,7 @@ __device__ __forceinline__ void chunk_count_block(const uint8_t *__restrict__ di
     // Every other block of the frame has ISSUED its total (it bumped the counter behind it); a total not visible yet
     // is a matter of the memory system's latency: looked at again, never waited for in any scheduling sense.
     uint32_t running = 0;
+    bool lost = false;  // a total that never became visible (cannot happen unless a count block died): bounded, reported in-band
     for (uint32_t base = 0; base < c.groups_per_frame; base += 512u) {  // eight totals per lane, requested together
       uint32_t v[8];
 #pragma unroll
@@ -1483,7 +1484,12 @@ __device__ __forceinline__ void chunk_count_block(const uint8_t *__restrict__ di
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t h = base + uint32_t(k) * 64u + lane;
-        while (v[k] == kChunkEmpty) {
+        for (uint32_t tries = 0; v[k] == kChunkEmpty; ++tries) {
+          if (tries == (1u << 22)) {  // (~1 s of looking: every launch must end)
+            lost = true;
+            v[k] = 0u;
+            break;
+          }
           __builtin_amdgcn_s_sleep(1);
           v[k] = __hip_atomic_load((gu32 *)(fs.gsum + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1500,8 +1506,9 @@ __device__ __forceinline__ void chunk_count_block(const uint8_t *__restrict__ di
         running += __builtin_amdgcn_readlane(incl, 63);
       }
     }
+    lost = __ballot(lost) != 0;
     if (lane == 0) {
-      if (counts) counts[f] = running;
+      if (counts) counts[f] = lost ? kCountTimedOut : running;
       __hip_atomic_store((gu32 *)fs.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
