@@ -88,7 +88,7 @@ struct QxSegs {
 // i.e. one copy per wave with no LDS or vector-memory traffic at all.
 struct QMat {
   double q[16];
-  // how the general kernel evaluates (tuning "general_q_form" / "reproject_form"):
+  // how the general kernel evaluates (d2pc_set_reproject_form; test hook "general_q_form" of d2pc_ext.h):
   //   0  OpenCV 3/4's association, bit for bit (default)
   //   1  fused multiply-adds (round 2's form)
   //   2  OpenCV 2.4's loop, bit for bit -- for a Q whose column increments are exact (q00 = 1, q01 = q10 = q20 = q30 = +0,

@@ -169,7 +169,7 @@ __device__ __forceinline__ float big_z_rule(float d, float Z) { return d == 3.40
 //     p /= h[3]                         ia = 1./h[3]; p[i] = float(p[i] * ia), the product formed in double
 // (no contraction: #pragma clang fp contract(off)).  Round 2 evaluated the rows with fused multiply-adds, which matched
 // neither published form where a dense Q makes a numerator cancel (tens of float ulp); that form stays behind the
-// tuning key "general_q_form" = 1 for comparison.  cv::stereoRectify's Q takes the specialised path below.
+// test hook "general_q_form" = 1 (d2pc_ext_set_test_hook) for comparison.  cv::stereoRectify's Q takes the specialised path below.
 __device__ __forceinline__ void reproject(const QArg<QK_GENERAL> &A, uint32_t u, uint32_t v, float d, float &X,
                                           float &Y, float &Z) {
   const double *q = A.m.q;
