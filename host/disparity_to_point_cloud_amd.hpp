@@ -87,6 +87,10 @@ class Disparity2PCloudT {
       throw std::runtime_error("bad calibration parameters");
     }
     if (verbose_) printf("stereoRectify\n");
+    // the header's policy: a library whose ABI version differs from the header this was compiled against is refused
+    if (d2pc_abi_version() != D2PC_ABI_VERSION)
+      throw std::runtime_error("libd2pc.so has ABI version " + std::to_string(d2pc_abi_version()) + ", this node was built against " +
+                               std::to_string(D2PC_ABI_VERSION));
     d2pc_config cfg;
     d2pc_config_init(&cfg);  // border 40 (cpp:70,72)
     cfg.device_id = device_id;
