@@ -89,7 +89,7 @@ struct d2pc_ctx {
   int parity_small = 0;          // PARITY kernel form: 0 = choose, 1 = one-shot blocks of 256 * pxt pixels (pxt 1, 2, 4), 2 = tiles walked by fewer blocks
   int blocks_per_cu = 128;
   int onepass_blocks_per_cu = 0;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each: 4 fit); 0 = choose per launch
-  int big_batch_algo = 2;          // COMPACT launches of >= 4 frames and >= 24,576 tiles: 2 = single pass (default: faster), 4 = chunked two-pass of one-shot blocks
+  int big_batch_algo = 2;          // COMPACT launches of >= 4 frames and >= 20,480 tiles: 2 = single pass (default: faster), 4 = chunked two-pass of one-shot blocks
   int chunk_mb = 96;               // algo 4: input bytes per chunk (MiB); the chunk must stay in the 256 MiB Infinity Cache for one launch
   int chunk_first_frames = 0;      // algo 4: frames of the first chunk (0 = an eighth of a chunk)
   int resident_stagger_pct = -1;   // algo 3, register-resident form: scale of the ramped start in % (0 = every block loads at once;
@@ -586,7 +586,10 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   // its pipeline fill -- measured crossover ~25k tiles (16 x 4K: 449 vs 495 us; 32 x 1080p: 196 vs 207;
   // 256 x 752x480: 278 vs 290; but 8 x 1080p: 68 vs 61) -- and needs a few frames in flight, because a
   // frame's ticket word serialises at ~18 ns per tile (one 4K frame: 72 vs 35 us)
-  const bool big_batch = g.n_frames >= 4 && g.total_tiles >= 24576;
+  // (round 4, profiles/r04_ab_midrange.txt: the crossover is where the input stops fitting the Infinity Cache between the two-pass
+  // form's two reads, ~160 MB = ~20k tiles of fp32 -- 6 x 4K (22.9k tiles): single pass 166 us, two-pass 184; 4 x 4K (15.3k): 117 / 114;
+  // 16 x 1080p (14.4k): 112 / 103.  The threshold was 24,576 before, which sent 6 x 4K the slower way.)
+  const bool big_batch = g.n_frames >= 4 && g.total_tiles >= 20480;
   // camera-size launches whose tiles are all resident at once take ONE launch (k_compact_resident) unless the call
   // is being captured (its epoch argument would freeze in the graph); one 1080p frame 16 -> ~8 us
   // ... in the ordinary tiles (k_compact_resident), or -- one or two 4K frames -- in blocks of 32 / 64 pixels per thread

@@ -85,7 +85,7 @@ typedef struct d2pc_config {
   int32_t mode;           /* d2pc_mode                                        */
   float min_disparity;    /* COMPACT only: also drop d <= this; -inf = off    */
   int32_t compact_algo;   /* 0 = library default: single pass (2) for launches
-                             of >= 4 frames and >= ~25k tiles; one launch of
+                             of >= 4 frames and >= ~20k tiles; one launch of
                              resident blocks (3) for launches of up to two 4K
                              frames that are not being captured; two-pass (1)
                              else.  1 = two-pass count/scan/scatter;

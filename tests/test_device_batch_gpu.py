@@ -93,7 +93,7 @@ def test_chunked_two_pass_whatever_the_chunking(chunk_mb, first, dtype):
 
 def test_default_algorithm_on_a_large_batch():
     """compact_algo = 0 picks the big-batch form (the chunked two-pass; tuning big_batch_algo = 2: the single pass) for big
-    launches (>= 4 frames, >= ~25k tiles): 30 frames of 1920x1080 (27k tiles) with three validity
+    launches (>= 4 frames, >= ~20k tiles): 30 frames of 1920x1080 (27k tiles) with three validity
     patterns, relaunched, against the oracle."""
     q = d2pc.make_q()
     kinds = ["holes", "blocky", "uniform"]
