@@ -622,22 +622,6 @@ def main():
             c2.check_async_error()
             del b2
             c2.close()
-        # the big batch through the chunked two-pass (compact_algo 4; one-shot blocks, no hand-off inside a launch): built on
-        # round 3's verdict, measured slower than the single pass -- kept in the line so that the negative stays visible
-        c2 = d2pc.Context(device_id=local_rank, border=40, mode=d2pc.MODE_COMPACT, q=q, compact_algo=4)
-        b2 = DeviceBatch(c2, a.frames, H4K, W4K, want_index=False, device=dev)
-        fill_batch(b2, rank, "holes")
-        b2.launch()
-        torch.cuda.synchronize()
-        npts = int(b2.counts.sum().item())
-        sp = spread(timed_rounds(b2, n_side, 3))
-        ab = algorithmic_bytes(b2, npts, False)
-        variants["compact_border40_30pct_holes_chunked_two_pass"] = {
-            "Mpixels_per_s": round(pixels_per_step / (sp["median"] * 1e-3) / 1e6, 1), "achieved_GBs": round(ab / (sp["median"] * 1e-3) / 1e9, 1),
-            "frac": round(ab / (sp["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms_avg": sp["median"], "kernel_ms_spread": sp,
-            "points_per_step": npts, "what": "compact_algo 4: k_compact_chunk launches (scatter of chunk i-1 + count of chunk i)"}
-        del b2
-        c2.close()
         # the whole device-resident callback body (cpp:55-85): 8-bit disparity ->
         # median 11x11 -> x1/8 -> reproject + pack, same 16 x 4K geometry
         c3 = d2pc.Context(device_id=local_rank, border=a.border, mode=d2pc.MODE_PARITY, q=q)

@@ -140,19 +140,22 @@ class D2pcError(RuntimeError):
         super().__init__(f"d2pc status {status} ({status_string(status)}): {message}")
 
 
-_lib = None
+_lib = None   # (kept for tools that reset it; the cache below is keyed by file name)
+_libs = {}
 
 
-def library_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+def library_path(variant=None) -> str:
+    return os.path.join(_HERE, _LIB_NAME if variant is None else "libd2pc_%s.so" % variant)
 
 
-def load_library():
-    """Load libd2pc.so.  Raises (never falls back) when it is not built."""
+def load_library(variant=None):
+    """Load libd2pc.so -- or, for `variant`, libd2pc_<variant>.so (tests and tools: "exp" is the experiment build of
+    `make exp`).  Raises (never falls back) when it is not built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    path = library_path()
+    path = library_path(variant)
+    fname = os.path.basename(path)
+    if fname in _libs:
+        return _libs[fname]
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -164,13 +167,13 @@ def load_library():
     except Exception:  # torch is plumbing only; the ABI works without it
         pass
     L = ctypes.CDLL(path)
-    if _LIB_NAME != "libd2pc.so":
+    if fname != "libd2pc.so":
         # tuning / A-B builds (tools only) may predate an entry point: calling a missing one raises
         class _Missing:
             argtypes = restype = None
 
             def __call__(self, *a):
-                raise AttributeError(f"{_LIB_NAME} does not export this entry point")
+                raise AttributeError(f"{fname} does not export this entry point")
         for name in ABI_SYMBOLS + EXT_SYMBOLS:
             if not hasattr(L, name):
                 setattr(L, name, _Missing())
@@ -251,7 +254,9 @@ def load_library():
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int or fn.restype is None:
             fn.restype = ctypes.c_int
-    _lib = L
+    _libs[fname] = L
+    if variant is None:
+        _lib = L
     return L
 
 
@@ -336,8 +341,9 @@ _NP2DT = {np.dtype(np.float32): DTYPE_F32, np.dtype(np.uint8): DTYPE_U8, np.dtyp
 class Context:
     """RAII wrapper of d2pc_ctx."""
 
-    def __init__(self, device_id=0, border=40, mode=MODE_PARITY, min_disparity=-np.inf, compact_algo=0, q=None):
-        self._L = load_library()
+    def __init__(self, device_id=0, border=40, mode=MODE_PARITY, min_disparity=-np.inf, compact_algo=0, q=None,
+                 variant=None):
+        self._L = load_library(variant)
         cfg = Config()
         self._check(self._L.d2pc_config_init(ctypes.byref(cfg)), None)
         cfg.device_id, cfg.border, cfg.mode = device_id, border, mode

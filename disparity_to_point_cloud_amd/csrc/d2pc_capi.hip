@@ -89,16 +89,20 @@ struct d2pc_ctx {
   int parity_small = 0;          // PARITY kernel form: 0 = choose, 1 = one-shot blocks of 256 * pxt pixels (pxt 1, 2, 4), 2 = tiles walked by fewer blocks
   int blocks_per_cu = 128;
   int onepass_blocks_per_cu = 0;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each: 4 fit); 0 = choose per launch
+#if D2PC_EXPERIMENTS
   int big_batch_algo = 2;          // COMPACT launches of >= 4 frames and >= 20,480 tiles: 2 = single pass (default: faster), 4 = chunked two-pass of one-shot blocks
   int chunk_mb = 96;               // algo 4: input bytes per chunk (MiB); the chunk must stay in the 256 MiB Infinity Cache for one launch
   int chunk_first_frames = 0;      // algo 4: frames of the first chunk (0 = an eighth of a chunk)
+  int resident_unbounded = 0;      // algo 3: admit launches of more blocks than are resident at once (see enqueue)
+  int general_q_form = 0;          // 0: OpenCV 3/4's association bit for bit; 1: fused multiply-adds (round 2's form)
+#else
+  static constexpr int big_batch_algo = 2, resident_unbounded = 0, general_q_form = 0;  // (the product: the single pass; bounded; OpenCV's association)
+#endif
   int resident_stagger_pct = -1;   // algo 3, register-resident form: scale of the ramped start in % (0 = every block loads at once;
                                    // -1 = choose: 50 for one frame that fills the device, else 0)
-  int resident_unbounded = 0;      // algo 3, experiment: admit launches of more blocks than are resident at once (see enqueue)
   int resident_pxt = 0;            // algo 3: pixels per thread of its blocks (0 = choose: the ordinary tile if the launch fits, else 32, else 64)
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
-  int general_q_form = 0;        // 0: OpenCV 3/4's association bit for bit; 1: fused multiply-adds (round 2's form)
   int reproject_form = 0;        // 0: per Q kind (specialised stereoRectify kernel / general kernel in OpenCV 3/4's form);
                                  // 24: OpenCV 2.4's loop bit for bit (Q with exact column increments); 4: OpenCV 3/4's form for every Q
   uint32_t qx_width = 0;         // reproject_form 24: columns the cached segment table below covers (0 = none)
@@ -354,6 +358,13 @@ int state_alloc(d2pc_ctx *ctx, const BufPool *pool, StateBuf &b, size_t need, si
     if (b.pending) D2PC_HIP(ctx, hipEventSynchronize(b.done));  // its last launch still reads and writes it
     b.pending = false;
   }
+  if (b.cap < need) {
+    // the buffer moves: whatever its last launch left in it is gone (the chunked two-pass would otherwise skip the clear of
+    // a buffer it believes still holds its counters and "empty" marks; advisor, round 4)
+    b.algo = 0;
+    b.chunk_sig = 0;
+    b.epoch = 0;
+  }
   int st = grow(ctx, &b.p, &b.cap, need);
   // fresh memory starts zeroed: k_compact_resident tells "published by THIS launch" from anything older by the epoch
   // in the word, and an uninitialised word could hold any value
@@ -479,7 +490,7 @@ int fill_q(d2pc_ctx *ctx, LaunchArgs &a, int width) {
   memcpy(a.q.q, ctx->q, sizeof a.q.q);
   a.qs = ctx->qs;
   a.q_kind = ctx->force_general_q ? QK_GENERAL : ctx->q_kind;
-  a.q.form = ctx->general_q_form == 1 ? 1u : 0u;
+  a.q.form = ctx->general_q_form == 1 ? 1u : 0u;  // (1: experiment build only)
   a.q.seg = QxSegs{};
   a.q.seg.n = 1;
   if (ctx->reproject_form == 0) return D2PC_OK;
@@ -629,6 +640,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     a.geom = gr;
     a.pxt = resident_pxt;
   }
+#if D2PC_EXPERIMENTS
   if (a.compact_algo == 4) {
     // chunked two-pass (k_compact_chunk): the geometry in its own 512-pixel tiles; chunks of whole frames whose input
     // stays in the Infinity Cache between the launch that counts it and the launch that scatters it
@@ -649,6 +661,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     a.chunk_first = ctx->chunk_first_frames > 0 ? uint32_t(ctx->chunk_first_frames) : uint32_t((per + 7) / 8);
     if (a.chunk_first > a.chunk_frames) a.chunk_first = a.chunk_frames;
   }
+#endif
   if (a.compact_algo == 2) {
     // the single-pass kernel is software-pipelined over a block's tiles: it
     // wants few, long-lived blocks (about what is resident), not many short ones
@@ -688,6 +701,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   int st = acquire_buf(ctx, ctx->states, stream, a.state_bytes, 0, fixed_state, &sb);
   if (st != D2PC_OK) return st;
   a.state = sb->p;
+#if D2PC_EXPERIMENTS
   if (a.compact_algo == 4) {
     // (tiles per frame, frames): they fix the groups, the padded words and the stride -- two shapes may share a 256-byte-rounded
     // stride and still keep their group totals in different words, and a stale word that is not "empty" would be taken for a total
@@ -695,6 +709,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     a.chunk_clear = sb->algo != 4 || sb->chunk_sig != sig;
     sb->chunk_sig = sig;
   }
+#endif
   sb->algo = a.compact_algo;
   sb->epoch = a.epoch;
   D2PC_HIP(ctx, launch_compact(a));
@@ -705,7 +720,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
 // Does Q have the structure cv::stereoRectify produces (hpp:104)?
 //   [1 0 0 cx; 0 1 0 cy; 0 0 0 f; 0 0 a b], zeros being +0.0 bit patterns.
 // Then the nine products with +0.0 / 1.0 are exact and the specialised kernel
-// returns bit-identical results (see reproject(QK_STEREO) in d2pc_kernels.hip).
+// returns bit-identical results (see reproject(QK_STEREO) in d2pc_pixel.hpp).
 void classify_q(d2pc_ctx *ctx) {
   const double *q = ctx->q;
   auto pz = [](double x) { uint64_t b; memcpy(&b, &x, 8); return b == 0; };
@@ -863,7 +878,7 @@ int d2pc_create(const d2pc_config *cfg, d2pc_ctx **out) {
   if (cfg->struct_size != sizeof(d2pc_config)) return D2PC_ERR_INVALID_ARG;
   if (cfg->border < 0 || cfg->border > 16384) return D2PC_ERR_INVALID_ARG;
   if (cfg->mode != D2PC_MODE_PARITY && cfg->mode != D2PC_MODE_COMPACT) return D2PC_ERR_INVALID_ARG;
-  if (cfg->compact_algo < 0 || cfg->compact_algo > 4) return D2PC_ERR_INVALID_ARG;
+  if (cfg->compact_algo < 0 || cfg->compact_algo > (D2PC_EXPERIMENTS ? 4 : 3)) return D2PC_ERR_INVALID_ARG;
   if (std::isnan(cfg->min_disparity)) return D2PC_ERR_INVALID_ARG;
   int n = d2pc_device_count();
   if (n <= 0 || cfg->device_id < 0 || cfg->device_id >= n) return D2PC_ERR_NO_DEVICE;
@@ -1063,20 +1078,22 @@ int d2pc_set_reproject_form(d2pc_ctx *ctx, int form) {
 
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   if (!ctx || !key) return D2PC_ERR_INVALID_ARG;
-  if (!strcmp(key, "pxt_parity") && (value == 0 || value == 1 || value == 2 || tile_shape_supported(value))) ctx->pxt_parity = value;
-  else if (!strcmp(key, "parity_small") && value >= 0 && value <= 2) ctx->parity_small = value;
+  if (!strcmp(key, "pxt_parity") && (value == 0 || value == 1 || value == 2 || (D2PC_EXPERIMENTS && tile_shape_supported(value)))) ctx->pxt_parity = value;
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 0 && value <= 64) ctx->onepass_blocks_per_cu = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
-  else if (!strcmp(key, "big_batch_algo") && (value == 2 || value == 4)) ctx->big_batch_algo = value;
   else if (!strcmp(key, "resident_stagger_pct") && value >= -1 && value <= 1000) ctx->resident_stagger_pct = value;
-  else if (!strcmp(key, "resident_unbounded") && (value == 0 || value == 1)) ctx->resident_unbounded = value;
   else if (!strcmp(key, "resident_pxt") && (value == 0 || value == 32 || value == 64 || tile_shape_supported(value))) ctx->resident_pxt = value;
+#if D2PC_EXPERIMENTS  // the laboratory's keys (libd2pc_exp.so): d2pc_ext.h, "experiment build"
+  else if (!strcmp(key, "parity_small") && value >= 0 && value <= 2) ctx->parity_small = value;
+  else if (!strcmp(key, "big_batch_algo") && (value == 2 || value == 4)) ctx->big_batch_algo = value;
+  else if (!strcmp(key, "resident_unbounded") && (value == 0 || value == 1)) ctx->resident_unbounded = value;
   else if (!strcmp(key, "chunk_mb") && value >= 1 && value <= 4096) ctx->chunk_mb = value;
   else if (!strcmp(key, "chunk_first_frames") && value >= 0 && value <= 65535) ctx->chunk_first_frames = value;
+#endif
   else if (!strcmp(key, "callback_chunks") && value >= 0 && value <= 64) ctx->cb_chunks = value;
   else if (!strcmp(key, "callback_fused") && (value == 0 || value == 1)) ctx->cb_fused = value;
   else if (!strcmp(key, "callback_fused_compact") && value >= 0 && value <= 2) ctx->cb_fused_compact = value;
@@ -1098,7 +1115,9 @@ int d2pc_ext_revision(void) { return D2PC_EXT_REVISION; }
 int d2pc_ext_set_test_hook(d2pc_ctx *ctx, const char *key, int value) {
   if (!ctx || !key) return D2PC_ERR_INVALID_ARG;
   if (!strcmp(key, "force_general_q") && (value == 0 || value == 1)) ctx->force_general_q = value;
+#if D2PC_EXPERIMENTS
   else if (!strcmp(key, "general_q_form") && (value == 0 || value == 1)) ctx->general_q_form = value;
+#endif
   else return fail(ctx, D2PC_ERR_INVALID_ARG, "unknown test hook %s=%d", key, value);
   return D2PC_OK;
 }
@@ -1106,9 +1125,9 @@ int d2pc_ext_set_test_hook(d2pc_ctx *ctx, const char *key, int value) {
 int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames) {
   if (!ctx) return D2PC_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
-  Geom g;  // the smallest supported tile (pxt = 4) gives the largest state
+  Geom g;  // the smallest supported tile gives the largest state
   int st = make_geom(ctx, D2PC_DTYPE_U8, 1.f, width, height, size_t(width), size_t(width) * height, n_frames,
-                     d2pc_roi_points(width, height, ctx->cfg.border), 4, &g);
+                     d2pc_roi_points(width, height, ctx->cfg.border), D2PC_EXPERIMENTS ? 4 : 8, &g);
   if (st != D2PC_OK) return st;
   // Guarantees ONE free (idle, not owned by a captured graph) buffer of this size, and makes it the
   // minimum size of every buffer allocated later.  Call it before each capture that contains a COMPACT launch.
@@ -1268,16 +1287,6 @@ int d2pc_membench_copy(d2pc_ctx *ctx, const void *d_src, void *d_dst, size_t byt
                                      ctx->membench_nt != 0, static_cast<hipStream_t>(stream)));
   return D2PC_OK;
 }
-
-#if defined(D2PC_CLEAR_WITH_MEMSET) && D2PC_CLEAR_WITH_MEMSET
-// experiment build only (tools/graph_memset_probe.py): the raw accumulators, pad[] included
-int d2pc_debug_read_stats(d2pc_ctx *ctx, void *out64) {
-  if (!ctx) return D2PC_ERR_INVALID_ARG;
-  DeviceGuard guard(ctx->device);
-  D2PC_HIP(ctx, hipMemcpy(out64, ctx->d_stats, sizeof(CompactStats), hipMemcpyDeviceToHost));
-  return D2PC_OK;
-}
-#endif
 
 #ifdef D2PC_DIAG
 // diagnostic build only: copy the 128-byte state header (phase timers) out

@@ -12,6 +12,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The shipped library holds the product's kernels only.  -DD2PC_EXPERIMENTS=1 (libd2pc_exp.so; `make exp`) adds the
+// laboratory: tile shapes other than the defaults, the tile-walking PARITY kernel of rounds 1-2, the chunked two-pass
+// (compact_algo 4), the register-resident form over more blocks than are resident, round 2's fused general-Q form.
+// tests/ and tools/ that exercise those load the experiment build; nothing in include/d2pc.h refers to them.
+#ifndef D2PC_EXPERIMENTS
+#define D2PC_EXPERIMENTS 0
+#endif
+
 namespace d2pc {
 
 constexpr int kBlock = 256;  // threads per workgroup (4 waves of 64)

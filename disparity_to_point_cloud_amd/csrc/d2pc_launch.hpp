@@ -1,5 +1,5 @@
 // d2pc_launch.hpp -- host-side launch interface between the C ABI
-// (d2pc_capi.hip) and the kernels (d2pc_kernels.hip).
+// (d2pc_capi.hip) and the kernels (d2pc_parity / _compact / _onepass / _callback / _median* / _fusion .hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -20,8 +20,8 @@ struct LaunchArgs {
   void *stats = nullptr;          // device: CompactStats of the context (single pass)
   int dtype = DT_F32;
   int pxt = 4;                    // ROI pixels per thread (tile = 256*pxt)
-  int compact_algo = 1;           // 1 two-pass, 2 single-pass, 3 one launch of resident blocks (k_compact_resident),
-                                  // 4 chunked two-pass of one-shot blocks (k_compact_chunk; geom in 512-pixel tiles)
+  int compact_algo = 1;           // 1 two-pass, 2 single-pass, 3 one launch of resident blocks (k_compact_resident[_lean]);
+                                  // experiment build: 4 chunked two-pass of one-shot blocks (k_compact_chunk; geom in 512-pixel tiles)
   uint32_t chunk_frames = 0;      // algo 4: frames per chunk, and frames of the first chunk (only counted, nothing
   uint32_t chunk_first = 0;       //         to overlap with: kept short)
   bool chunk_clear = false;       // algo 4: the state buffer was last used otherwise: zero its frame counters first
@@ -94,10 +94,15 @@ hipError_t launch_rotate_cw(RotateArgs a, hipStream_t stream);
 
 bool tile_shape_supported(int pxt);
 uint32_t frame_state_stride(uint32_t tiles_per_frame);
-// algo 4: bytes of state per frame for frames of `tiles_per_frame` 512-pixel tiles, and the words its group totals take
-uint32_t chunk_frame_state_stride(uint32_t tiles_per_frame, uint32_t *gsum_words);
 size_t compact_state_bytes(const Geom &g);
-hipError_t launch_parity(const LaunchArgs &a);
+hipError_t launch_parity(const LaunchArgs &a);          // d2pc_parity.hip
+hipError_t launch_onepass(const LaunchArgs &a);         // d2pc_onepass.hip (compact_algo 2: state clear + single pass)
+// zeroes a compaction state buffer and starts its header (d2pc_onepass.hip); also ahead of the tile-fused COMPACT callback kernels
+hipError_t launch_state_clear(void *state, size_t state_bytes, void *stats, hipStream_t stream);
+// experiment build only (d2pc_chunk.hip, compact_algo 4): bytes of state per frame for frames of `tiles_per_frame`
+// 512-pixel tiles, and the words its group totals take
+uint32_t chunk_frame_state_stride(uint32_t tiles_per_frame, uint32_t *gsum_words);
+hipError_t launch_compact_chunked(const LaunchArgs &a);
 // tile-fused callback body (bit-sliced k x k median + PARITY reprojection of the tile from LDS;
 // k_callback_bs): `m` carries the filter's geometry with the output rectangle = the ROI of a.geom; a.out_points,
 // a.out_index (nullable), a.counts (nullable), a.q*, a.stream as in launch_parity

@@ -1,5 +1,5 @@
 // d2pc_median_bs_tile.hpp -- the tile body of d2pc_median_bs.hip, shared with the tile-fused callback kernel
-// (k_callback_bs in d2pc_kernels.hip).
+// (k_callback_bs in d2pc_callback.hip).
 //
 // d2pc_median_bs.hip -- k x k median of an 8-bit image on gfx950, BIT-SLICED ACROSS PIXELS: the second
 // device form of cv::medianBlur(img, out, 11) at reference src/disparity_to_point_cloud.cpp:55-57

@@ -90,10 +90,8 @@ typedef struct d2pc_config {
                              frames that are not being captured; two-pass (1)
                              else.  1 = two-pass count/scan/scatter;
                              2 = single-pass counted hand-off; 3 = resident
-                             blocks (falls back where impossible); 4 = chunked
-                             two-pass of one-shot blocks (measured slower than
-                             2: DESIGN.md section 7).  Same bytes out whatever
-                             the value. */
+                             blocks (falls back where impossible).  Same bytes
+                             out whatever the value. */
   int32_t reserved[4];
 } d2pc_config;
 
@@ -176,7 +174,7 @@ int d2pc_set_q(d2pc_ctx *ctx, const double q[16]);
 int d2pc_get_q(const d2pc_ctx *ctx, double q_out[16]);
 int d2pc_set_border(d2pc_ctx *ctx, int border);
 int d2pc_set_mode(d2pc_ctx *ctx, int mode);
-/* Which cv::reprojectImageTo3D (cpp:67) the points reproduce.  The two OpenCV
+/* Which cv::reprojectImageTo3D (cpp:64) the points reproduce.  The two OpenCV
  * generations evaluate the same Q*[x y d 1]^T in different orders and differ
  * from each other by up to 1 float ulp (more where a numerator cancels):
  *   D2PC_FORM_DEFAULT  cv::stereoRectify's Q: a specialised kernel, <= 1 ulp
@@ -343,7 +341,7 @@ int d2pc_process_mono16(d2pc_ctx *ctx, const uint16_t *image, int width, int hei
  * frames never reach memory.  Everything else -- small launches -- is the filter
  * launch followed by the reprojection launch.  The results are the same bytes
  * either way (measurements: DESIGN.md section 5).
- * (Launch-shape knobs for experiments: d2pc_ext.h, "callback_fused", "callback_chunks".)
+ * (Launch-shape knobs: d2pc_set_tuning in d2pc_ext.h.)
  * In the two-launch form the filtered frames live in a scratch buffer that belongs
  * to the calling stream's work (one per stream in flight, like the compaction
  * state: double-buffered use on two streams is safe); it is grown on demand, so

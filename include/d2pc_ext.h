@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define D2PC_EXT_REVISION 4   /* round 4: split off d2pc.h; chunk_* / big_batch_algo keys; d2pc_ext_set_test_hook */
+#define D2PC_EXT_REVISION 5   /* round 5: the laboratory (experiment build) split from the product; 4: split off d2pc.h */
 int d2pc_ext_revision(void);
 
 /* ---- hipGraph capture plumbing ------------------------------------------------------------------------------ */
@@ -90,29 +90,35 @@ typedef struct d2pc_stage_times {
 int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
 
 /* Launch-shape tuning hook (no counterpart in the reference).  Results NEVER depend on it: every key below picks how
- * the same bytes are produced.  Keys: "big_batch_algo" (2 / 4: what compact_algo 0 takes for big batches), "chunk_mb"
- * (1..4096: input MiB per chunk of the chunked two-pass), "chunk_first_frames" (frames of its first chunk; 0 = an
- * eighth of a chunk), "pxt_parity" (ROI pixels per thread: 1, 2 = one-shot blocks of 256 / 512 pixels, 4, 8 or 16 = tiles
- * walked by a fixed grid; 0 = choose per launch: 2), "parity_small" (0/1/2: one-shot blocks off / also for 4 / default), "pxt_compact" (4, 8 or 16), "blocks_per_cu" (grid = blocks_per_cu x CUs, capped by
- * the tile count; 1..4096), "onepass_blocks_per_cu" (persistent blocks per CU of the single pass; 0 = choose:
- * 3 for 4K-class frames, 4 below), "no_vec_rows", "fuse_rows" (rows per wave of
- * d2pc_fuse_device: 0 = choose, else even 2..1024), "stage_timing" (0/1, see d2pc_last_stage_times),
- * "spin_timeout_ms" (1..40000: time budget of the single-pass compaction's hand-off waits),
- * "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
+ * the same bytes are produced.  Keys of the product library (libd2pc.so): "pxt_parity" (ROI pixels per thread of the
+ * one-shot PARITY blocks: 1 or 2; 0 = choose per launch), "pxt_compact" (8), "blocks_per_cu" (grid = blocks_per_cu x CUs,
+ * capped by the tile count; 1..4096), "onepass_blocks_per_cu" (persistent blocks per CU of the single pass; 0 = choose:
+ * 3 for 4K-class frames, 4 below), "resident_pxt" / "resident_stagger_pct" (shape and ramped start of the one-launch
+ * resident forms), "no_vec_rows", "fuse_rows" (rows per wave of d2pc_fuse_device: 0 = choose, else even 2..1024),
+ * "stage_timing" (0/1, see d2pc_last_stage_times), "spin_timeout_ms" (1..40000: time budget of the in-launch hand-off
+ * waits), "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
  * "callback_fused" (0/1, see d2pc_process_mono_device; default 1), "callback_fused_compact" (COMPACT mode: 0 = two
  * launches, 1 = one tile per block, 2 = persistent blocks that scatter one tile while filtering the next; default 2),
- * "callback_pipe_blocks_per_cu" (1..8, default 3), "membench_blocks_per_cu" (d2pc_membench_*: persistent blocks per CU, default 8; 0 = one block per
- * "membench_unroll" x 4 KiB), "membench_unroll" (1, 2 or 4 16-byte accesses per thread), "membench_nt" (0/1),
- * "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process / d2pc_process_mono8
- * without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose per launch,
- * 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes). */
+ * "callback_pipe_blocks_per_cu" (1..8, default 3), "membench_blocks_per_cu" (d2pc_membench_*: persistent blocks per
+ * CU, default 8; 0 = one block per "membench_unroll" x 4 KiB), "membench_unroll" (1, 2 or 4 16-byte accesses per thread),
+ * "membench_nt" (0/1), "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process /
+ * d2pc_process_mono8 without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose
+ * per launch, 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes).
+ *
+ * EXPERIMENT BUILD (libd2pc_exp.so = the same sources with -DD2PC_EXPERIMENTS=1, `make -C csrc exp`; what tests/ and
+ * tools/ load to re-run recorded negatives; never shipped, never what INTEGRATION.md links).  It adds, and only it
+ * accepts: d2pc_config.compact_algo = 4 (round 4's two-pass over Infinity-Cache-sized pieces of the batch, 15-25 % slower
+ * than the single pass: docs/HISTORY.md) with its keys "big_batch_algo" (2 / 4: what compact_algo 0 takes for big
+ * batches) and the two that size its pieces; "resident_unbounded" (0/1: the resident form over more blocks than are
+ * resident); "pxt_parity" 4 / 8 / 16 (the tile-walking PARITY kernel of rounds 1-2) and "parity_small"; "pxt_compact" 4 / 16;
+ * test hook "general_q_form" = 1 (round 2's fused evaluation of a general Q). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 
 /* TEST hooks that DO change the arithmetic, kept apart from the tuning keys for that reason (tests compare the two
  * routes to the same bytes with them; nothing else should call this):
  *   "force_general_q"  0/1: a cv::stereoRectify-structured Q goes through the general kernel as well
- *   "general_q_form"   0 = OpenCV 3/4's association (the product), 1 = round 2's fused multiply-adds (comparison only) */
+ *   "general_q_form"   experiment build only: 1 = round 2's fused multiply-adds instead of OpenCV 3/4's association */
 int d2pc_ext_set_test_hook(d2pc_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

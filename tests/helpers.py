@@ -1,6 +1,15 @@
 """Shared helpers for the parity tests (numpy only)."""
 import numpy as np
 
+
+
+def variant_for(algo=0, pxt=8, exp=False):
+    """Which build a test loads: the product libd2pc.so (None) or the experiment build of `make exp`, libd2pc_exp.so
+    ("exp").  compact_algo 4 (the chunked two-pass), tile shapes other than 2,048 pixels, the tile-walking PARITY kernel
+    and round 2's fused general-Q form exist only in the latter (include/d2pc_ext.h, "experiment build")."""
+    return "exp" if (algo == 4 or pxt != 8 or exp) else None
+
+
 DEFAULT_CALIB = dict(fx=714.24, fy=713.5, cx=376.0, cy=240.0, baseline=0.09, nx=752, ny=480)
 
 

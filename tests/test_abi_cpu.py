@@ -50,13 +50,41 @@ def test_stable_header_holds_no_tool_surface():
                  "d2pc_reserve_mono", "d2pc_release_graph_buffers", "d2pc_last_stage_times", "d2pc_ext_set_test_hook"):
         assert name not in stable
     assert "d2pc_set_reproject_form" in stable
+    # ... and nothing of the laboratory (round 4's verdict): the stable header names neither the experiment build's
+    # algorithm nor any of its keys
+    text = open(os.path.join(ROOT, "include", "d2pc.h")).read().lower()
+    for word in ("chunk", "big_batch", "unbounded", "experiment"):
+        assert word not in text, word
     lib = d2pc.load_library()
-    assert lib.d2pc_ext_revision() >= 4
+    assert lib.d2pc_ext_revision() >= 5
     for rel in ("ros/disparity_to_point_cloud_node.cpp", "host/multi_gpu.hpp", "host/image_prep.hpp", "host/pinned_allocator.hpp",
                 "host/replay_main.cpp"):
         assert "d2pc_ext.h" not in open(os.path.join(ROOT, rel)).read(), rel
     ext_calls = set(re.findall(r"\b(d2pc_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "host", "disparity_to_point_cloud_amd.hpp")).read()))
     assert ext_calls & set(capi.EXT_SYMBOLS) <= {"d2pc_set_tuning", "d2pc_last_stage_times"}
+
+
+def test_product_library_carries_no_laboratory():
+    """The shipped libd2pc.so holds the product's kernels only (< 6 MB); the chunked two-pass, the tile-walking PARITY
+    kernel and the 1,024- / 4,096-pixel tile shapes are instantiated in the experiment build (`make exp`) alone."""
+    import subprocess
+
+    def kernels(path):
+        out = subprocess.run(["strings", "-n", "12", path], capture_output=True, text=True, check=True).stdout
+        return set(re.findall(r"_ZN4d2pc\w+", out))
+
+    prod_path = capi.library_path()
+    exp_path = capi.library_path("exp")
+    assert os.path.getsize(prod_path) < 6 * 1024 * 1024, os.path.getsize(prod_path)
+    prod = kernels(prod_path)
+    assert prod, "no kernel names found"
+    assert not [k for k in prod if "k_compact_chunk" in k or "k_chunk_clear" in k]
+    assert not [k for k in prod if "16k_reproject_packI" in k]          # the tile-walking kernel
+    assert [k for k in prod if "k_reproject_pack_small" in k] and [k for k in prod if "k_compact_onepass" in k]
+    if os.path.exists(exp_path):
+        exp = kernels(exp_path)
+        assert [k for k in exp if "k_compact_chunk" in k] and [k for k in exp if "16k_reproject_packI" in k]
+        assert prod <= exp, sorted(prod - exp)[:5]
 
 
 def test_abi_version_and_status_strings():

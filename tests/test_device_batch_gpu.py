@@ -5,7 +5,7 @@ import pytest
 
 import disparity_to_point_cloud_amd as d2pc
 import oracle
-from helpers import assert_points_close, synth_disparity
+from helpers import assert_points_close, synth_disparity, variant_for
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -43,7 +43,7 @@ def test_c4_4k_compact_batch(algo):
     q = d2pc.make_q()
     kinds = ["uniform", "holes", "blocky", "holes"]
     frames = [synth_disparity(4, 10 + f, 3840, 2160, k) for f, k in enumerate(kinds)]
-    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo, variant=variant_for(algo)) as ctx:
         b = _batch(ctx, frames, want_index=True)
         for _ in range(3):  # relaunch: state must re-initialise every call
             b.launch()
@@ -75,7 +75,7 @@ def test_chunked_two_pass_whatever_the_chunking(chunk_mb, first, dtype):
             fr[rng.random((h, w)) < 0.3] = 0
         scale = 0.125 if dtype == "u8" else 1.0 / 64
     frames[4][:] = 0          # a frame without a single valid point
-    with d2pc.Context(q=q, border=3, mode=d2pc.MODE_COMPACT, compact_algo=4) as ctx:
+    with d2pc.Context(q=q, border=3, mode=d2pc.MODE_COMPACT, compact_algo=4, variant="exp") as ctx:
         ctx.set_tuning("chunk_mb", chunk_mb)
         ctx.set_tuning("chunk_first_frames", first)
         b = _batch(ctx, frames, want_index=True)
@@ -91,14 +91,17 @@ def test_chunked_two_pass_whatever_the_chunking(chunk_mb, first, dtype):
         assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"frame {f}")
 
 
-def test_default_algorithm_on_a_large_batch():
-    """compact_algo = 0 picks the big-batch form (the chunked two-pass; tuning big_batch_algo = 2: the single pass) for big
-    launches (>= 4 frames, >= ~20k tiles): 30 frames of 1920x1080 (27k tiles) with three validity
-    patterns, relaunched, against the oracle."""
+@pytest.mark.parametrize("big_batch_algo", [2, 4])
+def test_default_algorithm_on_a_large_batch(big_batch_algo):
+    """compact_algo = 0 picks the big-batch form -- the single pass -- for big launches (>= 4 frames, >= 20,480 tiles):
+    30 frames of 1920x1080 (27k tiles) with three validity patterns, relaunched, against the oracle.  (In the experiment
+    build the tuning key big_batch_algo = 4 sends such launches through the chunked two-pass instead: second case.)"""
     q = d2pc.make_q()
     kinds = ["holes", "blocky", "uniform"]
     frames = [synth_disparity(3, 40 + f, 1920, 1080, kinds[f % 3]) for f in range(30)]
-    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, variant=variant_for(big_batch_algo)) as ctx:
+        if big_batch_algo != 2:
+            ctx.set_tuning("big_batch_algo", big_batch_algo)
         b = _batch(ctx, frames, want_index=True)
         for _ in range(2):
             b.launch()
@@ -155,7 +158,7 @@ def test_compact_is_idempotent_and_sorted_at_full_size(form, general):
 def test_launch_on_side_stream_and_graph_capture(algo):
     q = d2pc.make_q()
     frames = [synth_disparity(2, f, 640, 480, "holes") for f in range(6)]
-    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo, variant=variant_for(algo)) as ctx:
         b = _batch(ctx, frames, want_index=True)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -195,7 +198,7 @@ def test_two_streams_in_flight_from_one_context_do_not_share_compaction_state(al
     q = d2pc.make_q()
     fa = [synth_disparity(3, 100 + f, 1920, 1080, "holes") for f in range(6)]
     fb = [synth_disparity(3, 200 + f, 1920, 1080, "blocky") for f in range(6)]
-    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo, variant=variant_for(algo)) as ctx:
         ba, bb = _batch(ctx, fa, want_index=True), _batch(ctx, fb, want_index=True)
         sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
         torch.cuda.synchronize()
@@ -219,7 +222,7 @@ def test_graph_replay_survives_a_larger_eager_launch(algo):
     q = d2pc.make_q()
     small = [synth_disparity(2, f, 640, 480, "holes") for f in range(4)]
     big = [synth_disparity(3, 300 + f, 1920, 1080, "holes") for f in range(8)]
-    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, compact_algo=algo, variant=variant_for(algo)) as ctx:
         bs = _batch(ctx, small, want_index=True)       # reserves state for the small batch only
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

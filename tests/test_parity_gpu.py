@@ -14,7 +14,7 @@ import pytest
 
 import disparity_to_point_cloud_amd as d2pc
 import oracle
-from helpers import assert_points_close, synth_disparity, ulp_distance
+from helpers import assert_points_close, synth_disparity, ulp_distance, variant_for
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +46,8 @@ def test_golden_exact_rational(golden, name):
     disp = golden[name + "__disp"]
     with ctx_for(q, border=border) as ctx:
         got = ctx.process(disp)
-        ctx.set_test_hook("general_q_form", 1)   # round 2's fused multiply-add evaluation of a general Q
+    with ctx_for(q, border=border, variant="exp") as ctx:
+        ctx.set_test_hook("general_q_form", 1)   # round 2's fused multiply-add evaluation of a general Q (experiment build)
         got_fma = ctx.process(disp)
     if name.endswith("dense_q"):
         # a GENERAL Q is evaluated in OpenCV 3/4's association, bit for bit (oracle FORM_CV4): two casts => within
@@ -207,6 +208,7 @@ def test_tile_shapes_agree_bitwise(q_default, pxt):
     disp = synth_disparity(3, 2, 500, 300, "holes")
     with ctx_for(q_default) as ctx:
         ref = ctx.process(disp)
+    with ctx_for(q_default, variant="exp") as ctx:   # the tile-walking kernel of rounds 1-2: experiment build
         ctx.set_tuning("pxt_parity", pxt)
         ctx.set_tuning("blocks_per_cu", 1)
         got = ctx.process(disp)
@@ -219,7 +221,7 @@ def test_tile_shapes_agree_bitwise(q_default, pxt):
 def test_compact_vs_oracle_small(q_default, kind, algo):
     disp = synth_disparity(3, 0, 640, 360, kind)
     wp, wi = oracle.reproject_compact(disp, q_default, border=40)
-    with ctx_for(q_default, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+    with ctx_for(q_default, mode=d2pc.MODE_COMPACT, compact_algo=algo, variant=variant_for(algo)) as ctx:
         gp, gi = ctx.process(disp, want_index=True)
         m = ctx.cloud_meta(len(gp))
     assert len(gp) == len(wp), "point count must be bit-exact"
@@ -234,7 +236,7 @@ def test_c3_1080p_30pct_invalid(q_default, algo):
     for kind in ("holes", "blocky"):
         disp = synth_disparity(3, 1, 1920, 1080, kind)
         wp, wi = oracle.reproject_compact(disp, q_default, border=40)
-        with ctx_for(q_default, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+        with ctx_for(q_default, mode=d2pc.MODE_COMPACT, compact_algo=algo, variant=variant_for(algo)) as ctx:
             gp, gi = ctx.process(disp, want_index=True)
         assert len(gp) == len(wp)
         assert np.array_equal(gi, wi)
@@ -254,7 +256,7 @@ def test_compact_edge_patterns(q_default, algo, pxt):
         "one_valid": np.where(np.arange(base.size).reshape(base.shape) == 12345, base, 0).astype(np.float32),
         "last_only": np.where(np.arange(base.size).reshape(base.shape) == base.size - 1, base, 0).astype(np.float32),
     }
-    with ctx_for(q_default, border=0, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+    with ctx_for(q_default, border=0, mode=d2pc.MODE_COMPACT, compact_algo=algo, variant=variant_for(algo, pxt)) as ctx:
         ctx.set_tuning("pxt_compact", pxt)
         for name, disp in patterns.items():
             wp, wi = oracle.reproject_compact(disp, q_default, border=0)
@@ -276,7 +278,7 @@ def test_compact_tiny_w_takes_exact_slow_path(algo):
     disp[rng.random(disp.shape) < 0.1] = 0.0
     wp, wi = oracle.reproject_compact(disp, q, border=0)
     assert 0.05 < len(wp) / disp.size < 0.95
-    with ctx_for(q, border=0, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+    with ctx_for(q, border=0, mode=d2pc.MODE_COMPACT, compact_algo=algo, variant=variant_for(algo)) as ctx:
         gp, gi = ctx.process(disp, want_index=True)
     assert np.array_equal(gi, wi)
     assert_points_close(gp, wp, max_ulp=MAX_ULP)
@@ -299,7 +301,10 @@ def test_general_and_stereo_kernels_agree_bitwise(q_default):
         c4, i4 = ctx.process(disp, want_index=True)
         wc4, wi4 = oracle.reproject_compact(disp, q_default, border=40, form=oracle.FORM_CV4)
         assert np.array_equal(i4, wi4) and np.array_equal(c4.view(np.uint32), wc4.view(np.uint32))
-        ctx.set_mode(d2pc.MODE_PARITY)
+    with ctx_for(q_default, variant="exp") as ctx:   # round 2's fused form exists in the experiment build only
+        a_exp = ctx.process(disp)
+        assert np.array_equal(a_exp.view(np.uint32), a.view(np.uint32)), "product and experiment build differ on the product's path"
+        ctx.set_test_hook("force_general_q", 1)
         ctx.set_test_hook("general_q_form", 1)
         b = ctx.process(disp)
         ctx.set_mode(d2pc.MODE_COMPACT)
@@ -346,10 +351,13 @@ def test_reproject_form_selects_one_opencv_generation_bit_for_bit(w, h, border, 
                 ctx.set_reproject_form(form)
                 ctx.set_test_hook("force_general_q", general)
                 _same_bits(ctx.process(disp), want, f"form {form} general={general} {w}x{h}")
-                ctx.set_tuning("pxt_parity", 8)   # the tile-walking kernel too
+            with ctx_for(q, border=border, variant="exp") as ctx:   # the tile-walking kernel too (experiment build)
+                ctx.set_reproject_form(form)
+                ctx.set_test_hook("force_general_q", general)
+                ctx.set_tuning("pxt_parity", 8)
                 _same_bits(ctx.process(disp), want, f"form {form} general={general} {w}x{h} (tiles)")
             for algo in (1, 2, 3, 4):
-                with ctx_for(q, border=border, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
+                with ctx_for(q, border=border, mode=d2pc.MODE_COMPACT, compact_algo=algo, variant=variant_for(algo)) as ctx:
                     ctx.set_reproject_form(form)
                     ctx.set_test_hook("force_general_q", general)
                     gp, gi = ctx.process(disp, want_index=True)

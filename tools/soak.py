@@ -5,6 +5,7 @@ stereoRectify-structured Q.  Not part of the test suites (minutes); run on the G
     python tools/soak.py [cases] [seed]
 """
 import os, sys, time
+os.environ.setdefault("D2PC_LIBRARY_VARIANT", "exp")   # draws from the laboratory too (compact_algo 4, tile shapes 4 / 16): the experiment build
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

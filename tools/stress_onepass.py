@@ -4,6 +4,7 @@ persistent blocks per CU, hole patterns), every launch compared BIT FOR BIT on t
 result (which has no in-launch synchronisation) and checked for the sticky timeout flag.
 GPU box:  python tools/stress_onepass.py [launches] [seed]"""
 import os, sys, time
+os.environ.setdefault("D2PC_LIBRARY_VARIANT", "exp")   # draws from the laboratory too (compact_algo 4, tile shapes 4 / 16): the experiment build
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
