@@ -94,6 +94,11 @@ def launch_if_needed(argv):
 
 if __name__ == "__main__":
     launch_if_needed(sys.argv[1:])  # before torch / libd2pc.so are imported
+    if "WORLD_SIZE" not in os.environ:
+        # the all-cores CPU column pins its OpenMP team (round 4's verdict: one unpinned 4-s sample ranged 824-1958 Mpixel/s
+        # on 128 cores); the variable must be in place before the first OpenMP runtime of the process initialises
+        os.environ.setdefault("OMP_PROC_BIND", "close")
+        os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -273,6 +278,24 @@ def compaction_counters(ctx):
             "twopass_fallbacks": st["twopass_fallbacks"]}
 
 
+def valu_issue(kernel_ms, key):
+    """The callback-body kernels are bound by VALU issue, not by HBM: next to their HBM fraction the line carries the
+    fraction of the chip's vector-issue slots they fill = VALU wave-instructions x 2 cycles (a wave64 instruction occupies
+    its SIMD-32 for two; fp64 and a few integer forms take four, so this is a LOWER bound of the slots really taken)
+    / (1,024 SIMDs x cycles of the launch at the clock the counter pass measured).  The instruction count per launch is
+    COPIED from the tracked counter passes (profiles/valu_issue.json, separate rocprofv3 --pmc runs of this build's
+    kernels), the time is this run's."""
+    prof = os.path.join(ROOT, "profiles", "valu_issue.json")
+    try:
+        t = json.load(open(prof))[key]
+    except Exception:
+        return {}
+    cycles = kernel_ms * 1e-3 * t["clock_ghz"] * 1e9 * 1024
+    return {"valu_issue_frac": round(t["valu_wave_insts_per_launch"] * 2 / cycles, 4),
+            "valu_wave_insts_per_launch": t["valu_wave_insts_per_launch"], "valu_issue_clock_ghz": t["clock_ghz"],
+            "valu_issue_source": t.get("source"), "valu_issue_profile_build": t.get("build")}
+
+
 def cpu_baseline(q, border, budget_s=12.0):
     """The CPU restatement of cpp:63-85 (oracle, kind "port") on the same 4K
     workload, single thread like the reference's ros::spin(); bounded sample."""
@@ -291,20 +314,29 @@ def cpu_baseline(q, border, budget_s=12.0):
     one = W4K * H4K * n / el / 1e6
     nt = oracle.max_threads()
     oracle.reproject(fr, q, border=border, threads=nt, out=buf)  # start the OpenMP team
-    t0 = time.perf_counter()
-    m = 0
-    while True:
-        oracle.reproject(fr, q, border=border, threads=nt, out=buf)
-        m += 1
-        el2 = time.perf_counter() - t0
-        if el2 > budget_s / 3:
-            break
-    allc = W4K * H4K * m / el2 / 1e6
+    samples = []  # three samples of ~budget/6 each; the median is reported (OMP_PROC_BIND=close, set at start-up)
+    m_total, el2_total = 0, 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m = 0
+        while True:
+            oracle.reproject(fr, q, border=border, threads=nt, out=buf)
+            m += 1
+            el2 = time.perf_counter() - t0
+            if el2 > budget_s / 6:
+                break
+        samples.append(W4K * H4K * m / el2 / 1e6)
+        m_total += m
+        el2_total += el2
+    allc = sorted(samples)[1]
+    m, el2 = m_total, el2_total
     return {
         "value": round(one, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
         "sample": f"{n} frames of 3840x2160 fp32 (config 4, border {border}), oracle/d2pc_oracle.c FORM_CV24 "
                   f"(gcc -O3 -march=x86-64-v3 -ffp-contract=off), {el:.1f} s",
-        "all_cores": {"value": round(allc, 2), "cores": nt, "sample": f"{m} frames, OpenMP over rows, {el2:.1f} s"},
+        "all_cores": {"value": round(allc, 2), "cores": nt,
+                      "samples": [round(x, 1) for x in samples], "omp_proc_bind": os.environ.get("OMP_PROC_BIND", ""),
+                      "sample": f"median of three samples ({m} frames, OpenMP over rows, {el2:.1f} s in all)"},
     }
 
 
@@ -495,10 +527,15 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"config 4: {a.frames} x 3840x2160 fp32 disparity frames per step, d~U(0.5,128), "
-                        f"border {a.border}, mode {a.mode}, one stream per GPU, Q broadcast from rank 0",
+                        f"border {a.border}, mode {a.mode}, one stream per GPU, Q broadcast from rank 0; "
+                        f"time-floored warm-up: the {a.warmup} warm-up steps are followed by untimed launches of the same step "
+                        f"until >= {a.heat_ms:g} ms of device time have passed (roofline.warmup_launches_actual), then exactly "
+                        f"{a.steps} timed steps",
             "frames_per_step": a.frames, "width": W4K, "height": H4K, "border": a.border, "mode": a.mode,
             "points_per_step": n_points,
             "collective_backend": multi_gpu.backend_name(),
+            # what the collective backend itself reports (an 8-GPU record shows RCCL saw 8 ranks)
+            "ranks_seen_by_backend": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -602,7 +639,7 @@ def main():
                 ("compact_1080p_30pct_holes_index_1frame", 1, W3, H3, "config 3 geometry; k_compact_resident (one launch, one resident block per 2048-pixel tile)"),
                 ("compact_1080p_30pct_holes_index_32frames", 32, W3, H3, "config 3 geometry; k_state_clear + k_compact_onepass"),
                 ("compact_4k_30pct_holes_index_1frame", 1, W4K, H4K, "k_compact_resident_lean<32>: one launch, 955 resident blocks of 8192 pixels, disparities in registers between count and scatter"),
-                ("compact_4k_30pct_holes_index_2frames", 2, W4K, H4K, "k_compact_resident_lean<64>: one launch, 956 resident blocks of 16384 pixels")):
+                ("compact_4k_30pct_holes_index_2frames", 2, W4K, H4K, "two 4K frames in one call: k_compact_resident_lean<32> twice, back to back (one launch of 16384-pixel blocks was 20 % slower: profiles/r05_ab_pair.txt)")):
             c2 = d2pc.Context(device_id=local_rank, border=40, mode=d2pc.MODE_COMPACT, q=q)
             b2 = DeviceBatch(c2, nfr, hv, wv, want_index=True, device=dev)
             for f in range(nfr):
@@ -643,8 +680,11 @@ def main():
 
         sp, sp2 = spread(timed_rounds(_Body(), n_side, 3)), spread(timed_rounds(_TwoLaunches(), n_side, 3))
         kms, kms2 = sp["median"], sp2["median"]
+        ab_cb = a.frames * b3.roi_n * 17   # 1 B read + 16 B written per ROI pixel (the window's halo re-reads come from cache)
         variants["callback_u8_median11_parity_border40"] = {
             "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
+            "achieved_GBs": round(ab_cb / (kms * 1e-3) / 1e9, 1), "frac": round(ab_cb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            **valu_issue(kms, "callback_parity"),
             "kernel_ms_spread": sp, "as_two_launches_ms_spread": sp2,
             "what": "d2pc_process_mono_device: k_callback_bs<11> (bit-sliced median of a tile + its points from LDS) per step",
             "as_two_launches_ms": round(kms2, 4),
@@ -688,8 +728,11 @@ def main():
                 rec[fused] = (sp, compaction_counters(c4))
             npts = int(b4.counts.sum().item())
             kms, kms2 = rec[2][0]["median"], rec[0][0]["median"]
+            ab_cc = a.frames * b4.roi_n * 1 + 20 * npts   # 1 B read per ROI pixel + (16 + 4) B per surviving point
             variants[f"callback_u8_median11_compact_30pct_zero_{hole_kind}"] = {
                 "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
+                "achieved_GBs": round(ab_cc / (kms * 1e-3) / 1e9, 1), "frac": round(ab_cc / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                **valu_issue(kms, "callback_compact_" + hole_kind),
                 "kernel_ms_spread": rec[2][0], "points_per_step": npts, "compaction_counters": rec[2][1],
                 "what": "d2pc_process_mono_device, COMPACT + indices: k_callback_bs_compact_pipe<11> (persistent blocks: median of "
                         "a tile, then the previous tile's surviving points in row-major order; row counts handed over inside the launch)",
@@ -705,6 +748,23 @@ def main():
         if not a.no_host_path:
             variants["host_path_pcie_inclusive_1x4K_parity"] = host_path_rates(q, a.border)
         out["variants_1gpu"] = variants
+        # scalars the driver's parser keeps (nested objects under `parsed` are dropped): the north-star's own kernels
+        r = out["roofline"]
+        r["compact_all_valid_frac"] = variants["compact_border40_all_valid"]["frac"]
+        r["compact_holes_frac"] = variants["compact_border40_30pct_holes"]["frac"]
+        r["compact_holes_index_frac"] = variants["compact_border40_30pct_holes_index"]["frac"]
+        r["compact_all_valid_index_frac"] = variants["compact_border40_all_valid_index"]["frac"]
+        r["compact_holes_ms"] = variants["compact_border40_30pct_holes"]["kernel_ms_avg"]
+        r["c3_32x1080p_frac"] = variants["compact_1080p_30pct_holes_index_32frames"]["frac"]
+        r["c3_1frame_us"] = round(variants["compact_1080p_30pct_holes_index_1frame"]["ms_per_launch"] * 1e3, 2)
+        r["c4_1frame_compact_us"] = round(variants["compact_4k_30pct_holes_index_1frame"]["ms_per_launch"] * 1e3, 2)
+        r["c4_2frames_compact_us"] = round(variants["compact_4k_30pct_holes_index_2frames"]["ms_per_launch"] * 1e3, 2)
+        r["c4_2frames_wait_us_per_tile"] = (variants["compact_4k_30pct_holes_index_2frames"]["compaction_counters"] or {}).get("wait_us_per_tile")
+        r["parity_u8_frac"] = variants["parity_u8_input_border40"]["frac"]
+        r["callback_parity_ms"] = variants["callback_u8_median11_parity_border40"]["kernel_ms_avg"]
+        r["callback_parity_frac"] = variants["callback_u8_median11_parity_border40"]["frac"]
+        r["callback_compact_ms"] = variants["callback_u8_median11_compact_30pct_zero_blocky"]["kernel_ms_avg"]
+        r["callback_compact_frac"] = variants["callback_u8_median11_compact_30pct_zero_blocky"]["frac"]
     if rank == 0 and world == 1 and not a.no_cpu:  # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(q, a.border)
     if rank == 0:

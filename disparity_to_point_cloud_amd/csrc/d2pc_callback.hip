@@ -374,7 +374,8 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
   __shared__ uint32_t s_next, s_exact;
   __shared__ uint32_t s_cnt[32], s_base[32];
   __shared__ uint32_t s_stat[3];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t tid0 = threadIdx.x;
+  const uint32_t tid = tid0, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
   const uint32_t f = blockIdx.x % g.n_frames;
   const CbCompactState cs(state, g, f, ma.tiles_y);
@@ -416,6 +417,14 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
   };
 
   while (cur != kNoTile || prev != kNoTile) {
+    // Everything derived from the thread index is formed AGAIN in every iteration (opaque: the compiler cannot relate this
+    // `tid` to the loop-invariant one).  Left to itself it hoists those values out of the loop -- the staging offsets of the
+    // row loads and the thread's table entry 1/W, Z, class -- and, because the bit-sliced select needs every register of
+    // the 168 that three waves per SIMD leave, parks them in scratch: 23-29 spilled VGPRs, ~25 scratch reloads per tile, each
+    // a dependent round trip in front of the loads and table stores it feeds.  One fp64 division per thread and TILE is
+    // cheaper: 16 x 4K with 30 % zero pixels + indices 766.8 -> 723.5 us (blocky), 813.9 -> 772.5 (iid), interleaved on one
+    // device (profiles/r05_ab_callback_nohoist.txt); 0 spilled VGPRs, 0 bytes of scratch (round 4's verdict, item 3a).
+    const uint32_t tid = opaque(tid0), lane = tid & 63u;
     uint32_t tk = 0, nxt = kNoTile;
     if (cur != kNoTile) {
       // the ticket of the tile after `cur`: its round trip runs under the filter
@@ -671,7 +680,7 @@ hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const v
   if (callback_compact_state_bytes(m.tiles_x, m.tiles_y, m.n_frames, &stride) != a.state_bytes || stride != a.geom.frame_state_stride ||
       a.geom.n_frames != m.n_frames)
     return hipErrorInvalidValue;
-  if (hipError_t e = launch_state_clear(a.state, a.state_bytes, a.stats, a.stream); e != hipSuccess) return e;
+  if (hipError_t e = launch_state_clear(a.state, a.state_bytes, a.stats, a.stream, a.keep_timeout); e != hipSuccess) return e;
   const uint8_t *s8 = static_cast<const uint8_t *>(src);
   float4 *o = static_cast<float4 *>(a.out_points);
   uint8_t *state = static_cast<uint8_t *>(a.state);

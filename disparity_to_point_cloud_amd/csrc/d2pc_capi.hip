@@ -39,6 +39,12 @@ struct StateBuf {
   int algo = 0;                  // algorithm of that launch: 2 = single pass (its header holds the timeout flag),
                                  // 3 = resident blocks (the flag holds the launch's epoch)
   uint32_t epoch = 0;            // algo 3: that launch's epoch
+  // dense single pass (algo 2): the buffer holds TWO states of pp_half bytes; a launch runs on one and zeroes the other
+  // inside its own launch, for the next launch on this buffer (no k_state_clear kernel in front of every call)
+  size_t pp_half = 0;            // bytes per half as the last such launch used them (0: none yet)
+  int pp_next = 0;               // the half the next launch takes, clean iff pp_clean
+  bool pp_clean = false;         // reset by every other use of the buffer (other algorithms, captures, reallocation)
+  size_t hdr_off = 0;            // where the header of the LAST launch lives (d2pc_check_async_error)
   uint64_t chunk_sig = 0;        // algo 4: tiles per frame and frames of that launch (its frame counters and "empty" marks sit
                                  // where the next launch of the same shape expects them)
   bool captured = false;         // a stream capture baked the pointer into a graph: never freed, moved or shared
@@ -89,6 +95,7 @@ struct d2pc_ctx {
   int parity_small = 0;          // PARITY kernel form: 0 = choose, 1 = one-shot blocks of 256 * pxt pixels (pxt 1, 2, 4), 2 = tiles walked by fewer blocks
   int blocks_per_cu = 128;
   int onepass_blocks_per_cu = 0;   // resident 5-wave blocks per CU (73 VGPRs, 33 KB LDS each: 4 fit); 0 = choose per launch
+  int onepass_form = 0;            // which single-pass kernel: 0 = choose (kDefaultOnepassForm), 1 / 2 / 3: see enqueue
 #if D2PC_EXPERIMENTS
   int big_batch_algo = 2;          // COMPACT launches of >= 4 frames and >= 20,480 tiles: 2 = single pass (default: faster), 4 = chunked two-pass of one-shot blocks
   int chunk_mb = 96;               // algo 4: input bytes per chunk (MiB); the chunk must stay in the 256 MiB Infinity Cache for one launch
@@ -100,6 +107,7 @@ struct d2pc_ctx {
 #endif
   int resident_stagger_pct = -1;   // algo 3, register-resident form: scale of the ramped start in % (0 = every block loads at once;
                                    // -1 = choose: 50 for one frame that fills the device, else 0)
+  int resident_pair = 0;           // algo 3: 1 = two 4K-class frames in ONE launch of 16,384-pixel blocks (0: two launches of 8,192-pixel blocks)
   int resident_pxt = 0;            // algo 3: pixels per thread of its blocks (0 = choose: the ordinary tile if the launch fits, else 32, else 64)
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;
@@ -156,6 +164,8 @@ struct d2pc_ctx {
 };
 
 namespace {
+
+constexpr int kDefaultOnepassForm = 2;  // profiles/r05_ab_onepass_forms_*.txt: never slower than form 1, 5-6 % faster with 30 % holes, 29 % with 90 %
 
 int fail(d2pc_ctx *ctx, int status, const char *fmt, ...) {
   if (ctx) {
@@ -364,6 +374,8 @@ int state_alloc(d2pc_ctx *ctx, const BufPool *pool, StateBuf &b, size_t need, si
     b.algo = 0;
     b.chunk_sig = 0;
     b.epoch = 0;
+    b.pp_clean = false;
+    b.hdr_off = 0;
   }
   int st = grow(ctx, &b.p, &b.cap, need);
   // fresh memory starts zeroed: k_compact_resident tells "published by THIS launch" from anything older by the epoch
@@ -412,6 +424,16 @@ int acquire_buf(d2pc_ctx *ctx, BufPool &pool, hipStream_t stream, size_t need, s
   if (capturing) {
     for (StateBuf *b : pool.bufs)  // an earlier launch of the same capture on the same stream: ordered inside the graph
       if (b->captured && b->capture_id == cid && b->bound && b->stream == stream && fits(b)) pick = b;
+    if (!pick)
+      for (StateBuf *b : pool.bufs)
+        // the capturing stream's OWN eager buffer (the flow d2pc.h documents: run the largest batch once, then capture on
+        // the same stream): whatever that run left in flight is ordered before the capture by the caller's stream, exactly
+        // as for the output buffers -- settle() could never prove it idle, because the stream it would ask is capturing now
+        // (advisor, round 4: the captured launch failed with "reserve it" although the buffer was there)
+        if ((b->p || b->p2) && !b->captured && b->bound && b->stream == stream && fits(b)) {
+          pick = b;
+          b->dirty = b->pending = false;
+        }
     if (!pick)
       for (StateBuf *b : pool.bufs)
         if ((b->p || b->p2) && !b->captured && fits(b) && state_idle(*b) && (!pick || b->cap < pick->cap)) pick = b;
@@ -593,6 +615,28 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   }
   if (!d_counts) return fail(ctx, D2PC_ERR_INVALID_ARG, "COMPACT mode needs a d_counts buffer");
   a.pxt = int(g.pxt);
+  // TWO frames that fit the resident blocks only as one launch of 16,384-pixel blocks (two 4K frames): two launches of
+  // 8,192-pixel blocks, back to back on the stream, instead.  Measured on the driver's device in round 4: 65.6 us for the
+  // pair in one launch (every block twice as long in its read-then-write chain, no ramped start: 9 us of waiting per block)
+  // against 2 x 27.0 us; the back-to-back launches leave no gap since the buffers' events are recorded lazily.
+  // Tuning "resident_pair" = 1 keeps the one launch (tools/ab_resident.sh).
+  if (g.n_frames == 2 && !force_algo && (ctx->cfg.compact_algo == 0 || ctx->cfg.compact_algo == 3) && !ctx->resident_pxt &&
+      !ctx->resident_pair && !capture_info(stream, nullptr)) {
+    const uint32_t cap = uint32_t(ctx->cu_count * kResidentBlocksPerCu);
+    const uint32_t tpf32 = (g.roi_n + uint32_t(kBlock * 32) - 1u) / uint32_t(kBlock * 32);
+    if (2u * g.tiles_per_frame > cap && 2u * tpf32 > cap && tpf32 <= cap) {
+      for (uint32_t f = 0; f < 2u; ++f) {
+        Geom g1 = g;
+        g1.n_frames = 1;
+        g1.total_tiles = g1.tiles_per_frame;
+        int st1 = enqueue(ctx, g1, static_cast<const uint8_t *>(d_disp) + uint64_t(f) * g.in_frame_stride, dtype,
+                          static_cast<uint8_t *>(d_out) + uint64_t(f) * g.out_frame_stride * 16u,
+                          d_idx ? d_idx + uint64_t(f) * g.out_frame_stride : nullptr, d_counts + f, stream, fixed_state, 0);
+        if (st1 != D2PC_OK) return st1;
+      }
+      return D2PC_OK;
+    }
+  }
   // default (0): the single pass (one read of the input) wins once a launch is big enough to amortise
   // its pipeline fill -- measured crossover ~25k tiles (16 x 4K: 449 vs 495 us; 32 x 1080p: 196 vs 207;
   // 256 x 752x480: 278 vs 290; but 8 x 1080p: 68 vs 61) -- and needs a few frames in flight, because a
@@ -667,16 +711,31 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     // wants few, long-lived blocks (about what is resident), not many short ones
     // interleaved sweeps on two devices (profiles/r02_ab_onepass_v2_vs_r1.txt): 4K frames run 1-3 % faster with 3
     // blocks per CU (fewer failed polls), 1080p-class frames 1-4 % faster with 4
-    const int per_cu = ctx->onepass_blocks_per_cu ? ctx->onepass_blocks_per_cu : (g.tiles_per_frame >= 2048 ? 3 : 4);
+    // which single-pass kernel (tuning "onepass_form"; same bytes out): 2 = the count phase packs the survivors, the scatter
+    // phase runs dense (round 5: the product's); experiment build: 1 = raw tiles in LDS, every pixel decided in both phases
+    // (rounds 2-4), 3 = form 2 with 8 worker waves on tiles of 4,096 pixels, 4 = form 2 with the control wave as the loader
+    a.onepass_form = ctx->onepass_form ? ctx->onepass_form : kDefaultOnepassForm;
+    const int form_pxt = a.onepass_form == 3 ? 16 : a.onepass_form >= 2 ? 8 : int(g.pxt);
+    if (form_pxt != int(g.pxt)) {
+      Geom gf = g;
+      retile(&gf, form_pxt);
+      a.geom = gf;
+      a.pxt = form_pxt;
+    }
+    const int dflt_per_cu = a.onepass_form == 3 ? 2 : (a.geom.tiles_per_frame >= 2048 ? 3 : 4);
+    const int per_cu = ctx->onepass_blocks_per_cu ? ctx->onepass_blocks_per_cu : dflt_per_cu;
     const uint32_t persistent = uint32_t(ctx->cu_count) * uint32_t(per_cu);
-    a.grid = g.total_tiles < persistent ? g.total_tiles : persistent;
-    if (a.grid < g.n_frames) a.compact_algo = 1;  // more frames than blocks: every block serves one frame only
+    a.grid = a.geom.total_tiles < persistent ? a.geom.total_tiles : persistent;
+    if (a.grid < g.n_frames) {  // more frames than blocks: every block serves one frame only
+      a.compact_algo = 1;
+      a.geom = g;
+      a.pxt = int(g.pxt);
+    }
   }
   if (a.compact_algo == 3) {
     a.grid = a.geom.total_tiles;
     a.epoch = ctx->resident_epoch++;
     if (ctx->resident_epoch >= kEpochEnd) {  // (once in 2^30 launches: start over from clean state)
-      ctx->resident_epoch = kEpochBase;
       std::vector<StateBuf *> all(ctx->states.bufs);
       for (PipeSlot &sl : ctx->slots) all.push_back(&sl.st);  // the pipeline slots' own state buffers carry epochs too
       for (StateBuf *b : all)
@@ -687,6 +746,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
           D2PC_HIP(ctx, hipMemsetAsync(b->p, 0, b->cap, nullptr));
           D2PC_HIP(ctx, hipStreamSynchronize(nullptr));
         }
+      ctx->resident_epoch = kEpochBase;  // (only now: a failure above leaves the counter past the end and the next launch tries again)
     }
   }
   if (a.compact_algo == 1) {  // (the two-pass grid is the default one computed above)
@@ -697,10 +757,28 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   }
   a.state_bytes = compact_state_bytes(a.geom);
   a.stats = ctx->d_stats;
+  // the dense single pass cleans up for its successor: two states per buffer (see StateBuf::pp_*)
+  const bool self_clean = a.compact_algo == 2 && a.onepass_form == 2;
+  const size_t half = (a.state_bytes + 255) & ~size_t(255);
   StateBuf *sb = nullptr;
-  int st = acquire_buf(ctx, ctx->states, stream, a.state_bytes, 0, fixed_state, &sb);
+  int st = acquire_buf(ctx, ctx->states, stream, self_clean ? 2 * half : a.state_bytes, 0, fixed_state, &sb);
   if (st != D2PC_OK) return st;
   a.state = sb->p;
+  if (self_clean) {
+    const bool clean = sb->pp_clean && sb->pp_half == half && !sb->captured;
+    const int h = clean ? sb->pp_next : 0;
+    a.state = static_cast<uint8_t *>(sb->p) + size_t(h) * half;
+    a.state_is_clean = clean;
+    // a captured launch replays on the half baked into it: it keeps the clear kernel in front and cleans nothing
+    a.state_other = sb->captured ? nullptr : static_cast<uint8_t *>(sb->p) + size_t(h ^ 1) * half;
+    sb->pp_half = half;
+    sb->pp_next = h ^ 1;
+    sb->pp_clean = !sb->captured;
+    sb->hdr_off = size_t(h) * half;
+  } else {
+    sb->pp_clean = false;
+    sb->hdr_off = 0;
+  }
 #if D2PC_EXPERIMENTS
   if (a.compact_algo == 4) {
     // (tiles per frame, frames): they fix the groups, the padded words and the stride -- two shapes may share a 256-byte-rounded
@@ -1082,10 +1160,12 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 0 && value <= 64) ctx->onepass_blocks_per_cu = value;
+  else if (!strcmp(key, "onepass_form") && (value == 0 || value == 2 || (D2PC_EXPERIMENTS && value >= 1 && value <= 4))) ctx->onepass_form = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;
   else if (!strcmp(key, "resident_stagger_pct") && value >= -1 && value <= 1000) ctx->resident_stagger_pct = value;
+  else if (!strcmp(key, "resident_pair") && (value == 0 || value == 1)) ctx->resident_pair = value;
   else if (!strcmp(key, "resident_pxt") && (value == 0 || value == 32 || value == 64 || tile_shape_supported(value))) ctx->resident_pxt = value;
 #if D2PC_EXPERIMENTS  // the laboratory's keys (libd2pc_exp.so): d2pc_ext.h, "experiment build"
   else if (!strcmp(key, "parity_small") && value >= 0 && value <= 2) ctx->parity_small = value;
@@ -1131,7 +1211,8 @@ int d2pc_reserve(d2pc_ctx *ctx, int width, int height, int n_frames) {
   if (st != D2PC_OK) return st;
   // Guarantees ONE free (idle, not owned by a captured graph) buffer of this size, and makes it the
   // minimum size of every buffer allocated later.  Call it before each capture that contains a COMPACT launch.
-  return reserve_buf(ctx, ctx->states, compact_state_bytes(g), 0);
+  // (twice: the dense single pass keeps two states per buffer -- one in use, one it cleans for its successor)
+  return reserve_buf(ctx, ctx->states, 2 * ((compact_state_bytes(g) + 255) & ~size_t(255)), 0);
 }
 
 int d2pc_reserve_mono(d2pc_ctx *ctx, int dtype, int width, int height, int n_frames) {
@@ -1209,7 +1290,7 @@ static int state_timed_out(d2pc_ctx *ctx, const StateBuf &b, bool *timed_out) {
   *timed_out = false;
   if (!b.p || (b.algo != 2 && b.algo != 3)) return D2PC_OK;  // the two-pass form has no in-launch hand-off and never reads the flag
   StateHeader h;
-  D2PC_HIP(ctx, hipMemcpy(&h, b.p, sizeof h, hipMemcpyDeviceToHost));
+  D2PC_HIP(ctx, hipMemcpy(&h, static_cast<const uint8_t *>(b.p) + b.hdr_off, sizeof h, hipMemcpyDeviceToHost));
   // single pass: its state clear zeroed the flag; resident blocks: nothing zeroes it, a give-up stores the launch's epoch
   *timed_out = b.algo == 2 ? h.timeout != 0 : h.timeout == b.epoch;
   return D2PC_OK;
@@ -1297,7 +1378,7 @@ int d2pc_debug_read_header(d2pc_ctx *ctx, void *out64) {
       if (b->p && b->algo == 2) last = b;
   if (!last) return D2PC_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
-  D2PC_HIP(ctx, hipMemcpy(out64, last->p, sizeof(StateHeader), hipMemcpyDeviceToHost));
+  D2PC_HIP(ctx, hipMemcpy(out64, static_cast<const uint8_t *>(last->p) + last->hdr_off, sizeof(StateHeader), hipMemcpyDeviceToHost));
   return D2PC_OK;
 }
 #endif
@@ -1707,6 +1788,7 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
             if ((st = make_geom(ctx, D2PC_DTYPE_U8, scale, width, height, kin_pitch, kin_frame, ns, out_frame_stride, pxt, &gs)) != D2PC_OK)
               return st;
             LaunchArgs as = a;
+            as.keep_timeout = s0 > 0;  // one flag for the whole call: a later sub-batch's state clear must not wipe an earlier one's give-up
             MedianArgs ms = m;
             ms.n_frames = uint32_t(ns);
             as.out_points = static_cast<uint8_t *>(a.out_points) + size_t(s0) * out_frame_stride * 16;
@@ -1720,6 +1802,8 @@ extern "C" int d2pc_process_mono_device(d2pc_ctx *ctx, const void *d_image, int 
             if ((st = acquire_buf(ctx, ctx->states, sr, as.state_bytes, 0, nullptr, &sb)) != D2PC_OK) return st;
             as.state = sb->p;
             sb->algo = 2;  // its header carries the hand-off's timeout flag, like the single pass's
+            sb->pp_clean = false;
+            sb->hdr_off = 0;
             as.geom = gs;
             as.compact_algo = 1;
             if (ctx->cb_fused_compact == 2) {

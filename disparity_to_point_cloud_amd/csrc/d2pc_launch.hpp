@@ -17,6 +17,8 @@ struct LaunchArgs {
   uint32_t *counts = nullptr;     // device, nullable (required in COMPACT)
   void *state = nullptr;          // device: compaction state (COMPACT)
   size_t state_bytes = 0;
+  void *state_other = nullptr;    // dense single pass: the buffer's other half, zeroed by this launch for the next one (nullable)
+  bool state_is_clean = false;    // ... and `state` was left clean by the previous launch: no k_state_clear in front
   void *stats = nullptr;          // device: CompactStats of the context (single pass)
   int dtype = DT_F32;
   int pxt = 4;                    // ROI pixels per thread (tile = 256*pxt)
@@ -26,6 +28,10 @@ struct LaunchArgs {
   uint32_t chunk_first = 0;       //         to overlap with: kept short)
   bool chunk_clear = false;       // algo 4: the state buffer was last used otherwise: zero its frame counters first
   uint32_t epoch = 0;             // algo 3: this launch's epoch (kEpochBase <= epoch < kEpochEnd)
+  int onepass_form = 1;           // algo 2: 1 = raw tiles in LDS, every pixel decided twice (k_compact_onepass); 2 / 3 = survivors packed by
+                                  // the count phase, dense scatter, 4 / 8 worker waves (k_compact_onepass_dense; geom.pxt = 8 / 16)
+  bool keep_timeout = false;      // tile-fused COMPACT callback kernels: the state clear keeps the header's timeout flag (a
+                                  // later sub-batch of ONE call shares the buffer and must not wipe an earlier one's give-up)
   bool parity_small = false;      // PARITY: one-shot blocks of 256 * pxt pixels (pxt 1, 2 or 4), k_reproject_pack_small
   bool vec_rows = false;          // fp32 rows fetchable 16 B per lane (alignment checked by the host)
   uint32_t grid = 1;
@@ -98,7 +104,7 @@ size_t compact_state_bytes(const Geom &g);
 hipError_t launch_parity(const LaunchArgs &a);          // d2pc_parity.hip
 hipError_t launch_onepass(const LaunchArgs &a);         // d2pc_onepass.hip (compact_algo 2: state clear + single pass)
 // zeroes a compaction state buffer and starts its header (d2pc_onepass.hip); also ahead of the tile-fused COMPACT callback kernels
-hipError_t launch_state_clear(void *state, size_t state_bytes, void *stats, hipStream_t stream);
+hipError_t launch_state_clear(void *state, size_t state_bytes, void *stats, hipStream_t stream, bool keep_timeout = false);
 // experiment build only (d2pc_chunk.hip, compact_algo 4): bytes of state per frame for frames of `tiles_per_frame`
 // 512-pixel tiles, and the words its group totals take
 uint32_t chunk_frame_state_stride(uint32_t tiles_per_frame, uint32_t *gsum_words);

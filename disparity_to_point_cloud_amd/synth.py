@@ -4,7 +4,12 @@ import numpy as np
 
 
 def frame_seed(config_id: int, frame_id: int) -> int:
-    """seed = 0xD2C00000 + config_id*1000 + frame_id."""
+    """seed = 0xD2C00000 + config_id*1000 + frame_id.
+
+    The SEED is the survey's; the GENERATOR behind it is numpy's default (PCG64), because numpy has no 64-bit Mersenne
+    twister (`numpy.random.MT19937` is the 32-bit one).  The C++ harness (host/multi_gpu.hpp) draws its frames from
+    `std::mt19937_64` as the survey prescribes.  So Python-side and C++-side frames of one seed DIFFER: the two
+    harnesses never exchange frames by seed -- tests hand frames to the C++ harness as files (tests/test_host_cpp.py)."""
     return 0xD2C00000 + config_id * 1000 + frame_id
 
 

@@ -13,7 +13,7 @@ class DeviceBatch:
     """Pre-allocated device buffers for a batch of equally sized frames."""
 
     def __init__(self, ctx: capi.Context, n_frames: int, height: int, width: int, dtype=torch.float32,
-                 want_index=False, device="cuda:0"):
+                 want_index=False, device="cuda:0", reserve=True):
         cfg = ctx.config()
         self.ctx, self.n_frames, self.height, self.width = ctx, n_frames, height, width
         self.roi_n = capi.roi_points(width, height, cfg.border)
@@ -25,7 +25,8 @@ class DeviceBatch:
         self.index = (torch.empty((n_frames, self.stride), dtype=torch.int32, device=self.device)
                       if want_index else None)
         self.counts = torch.zeros((n_frames,), dtype=torch.int32, device=self.device)
-        ctx.reserve(width, height, n_frames)
+        if reserve:   # (so that a capture finds its compaction state; False: the first eager launch allocates it)
+            ctx.reserve(width, height, n_frames)
 
     def launch(self, scale=1.0, stream=None):
         """Enqueue one pass over the whole batch on `stream` (default: torch's

@@ -57,6 +57,7 @@ class Disparity2PCloudT {
   double Q_di_[16];
   bool have_q_di_ = false;
   d2pc_ctx *ctx_di_ = nullptr;
+  size_t frames_dropped_ = 0;
   int device_id_ = 0, mode_ = D2PC_MODE_PARITY;
   Publisher p_cloud_pub_;
   bool verbose_ = false;
@@ -112,6 +113,8 @@ class Disparity2PCloudT {
 
   const double *Q() const { return Q_; }
   d2pc_ctx *context() { return ctx_; }
+  // frames a callback could not convert and dropped (see drop_frame below)
+  size_t frames_dropped() const { return frames_dropped_; }
 
   // cpp:46-92
   void DisparityCb(const typename Image::ConstPtr &msg) {
@@ -142,9 +145,7 @@ class Disparity2PCloudT {
                                     size_t(msg->step), 11, 1.0f / 8.0f, output.data.data(), nullptr, cap, &n)
               : d2pc_process_mono8(ctx_, median_filtered.pix.data(), width, height, size_t(width),
                                    gpu_median_ ? 11 : 0, 1.0f / 8.0f, output.data.data(), nullptr, cap, &n);
-    if (st != D2PC_OK)
-      throw std::runtime_error(std::string("d2pc_process_mono8/16: ") + d2pc_status_string(st) + ": " +
-                               d2pc_last_error(ctx_));
+    if (drop_frame(st, "d2pc_process_mono8/16", ctx_)) return;
     output.data.resize(n * 16);
     if (verbose_) printf("Cloud size: %zu\n", n);  // cpp:82
     d2pc_stage_times tm;
@@ -163,6 +164,7 @@ class Disparity2PCloudT {
   // the fp32 seam.  In COMPACT mode points with d <= min_disparity are dropped (stereo_image_proc's rule).
   void DisparityImageCb(const typename DisparityImage::ConstPtr &msg) {
     const Image &im = msg->image;
+    // a malformed MESSAGE is an exception, as a malformed sensor_msgs/Image is for cv_bridge::toCvCopy (cpp:50)
     if (im.encoding != "32FC1") throw std::runtime_error("DisparityImage.image must be 32FC1, got [" + im.encoding + "]");
     if (im.is_bigendian) throw std::runtime_error("big-endian 32FC1 images are not supported");
     if (im.step < 4 * im.width || im.data.size() < size_t(im.step) * im.height)
@@ -176,32 +178,46 @@ class Disparity2PCloudT {
       cfg.device_id = device_id_;
       cfg.mode = mode_;
       const int st = d2pc_create(&cfg, &ctx_di_);
-      if (st != D2PC_OK) throw std::runtime_error(std::string("d2pc_create (DisparityImage): ") + d2pc_status_string(st));
-      check_di(d2pc_set_reproject_form(ctx_di_, int(reproject_form_)), "~reproject_form");
+      if (st != D2PC_OK) {
+        ctx_di_ = nullptr;
+        (void)drop_frame(st, "d2pc_create (DisparityImage)", nullptr);
+        return;
+      }
+      if (drop_frame(d2pc_set_reproject_form(ctx_di_, int(reproject_form_)), "~reproject_form", ctx_di_)) return;
     }
     bool same = have_q_di_;
     for (int i = 0; i < 16 && same; ++i) same = q[i] == Q_di_[i];
     if (!same) {  // recalibration: cameras rarely change f or T between frames
       for (int i = 0; i < 16; ++i) Q_di_[i] = q[i];
-      check_di(d2pc_set_q(ctx_di_, Q_di_), "d2pc_set_q");
+      have_q_di_ = false;
+      if (drop_frame(d2pc_set_q(ctx_di_, Q_di_), "d2pc_set_q", ctx_di_)) return;
       have_q_di_ = true;
     }
-    check_di(d2pc_set_min_disparity(ctx_di_, msg->min_disparity), "d2pc_set_min_disparity");
+    if (drop_frame(d2pc_set_min_disparity(ctx_di_, msg->min_disparity), "d2pc_set_min_disparity", ctx_di_)) return;
     PointCloud2 output;
     const size_t cap = d2pc_roi_points(int(im.width), int(im.height), 40);
     output.data.resize(cap * 16);
     size_t n = 0;
-    check_di(d2pc_process(ctx_di_, im.data.data(), D2PC_DTYPE_F32, 1.0f, int(im.width), int(im.height), size_t(im.step),
-                          output.data.data(), nullptr, cap, &n),
-             "d2pc_process");
+    if (drop_frame(d2pc_process(ctx_di_, im.data.data(), D2PC_DTYPE_F32, 1.0f, int(im.width), int(im.height), size_t(im.step),
+                                output.data.data(), nullptr, cap, &n),
+                   "d2pc_process", ctx_di_))
+      return;
     output.data.resize(n * 16);
     finish_and_publish(output, n, msg->header.stamp);
   }
 
  private:
-  void check_di(int st, const char *what) {
-    if (st != D2PC_OK)
-      throw std::runtime_error(std::string(what) + ": " + d2pc_status_string(st) + ": " + d2pc_last_error(ctx_di_));
+  // A frame the DEVICE side could not convert (any status but D2PC_OK from the C ABI) is logged and DROPPED; the node
+  // lives on and publishes the next one.  With the subscriber's queue depth of 1 (hpp:78) dropping a frame is what the
+  // reference does to every frame that arrives while a callback runs; dying is what an uncaught cv::Exception would do
+  // to it (no try/catch in cpp:46-92), and a transient device error is no reason to take the camera's node down.
+  // Construction failures (no device, bad calibration, ABI mismatch) still throw: nothing could ever be published.
+  bool drop_frame(int st, const char *what, d2pc_ctx *ctx) {
+    if (st == D2PC_OK) return false;
+    fprintf(stderr, "[disparity_to_point_cloud] %s: %s: %s -- frame dropped\n", what, d2pc_status_string(st),
+            ctx ? d2pc_last_error(ctx) : "");
+    ++frames_dropped_;
+    return true;
   }
 
   // cpp:79-90

@@ -11,6 +11,10 @@
 //        ONE node with both topics live: DisparityImageCb, then DisparityCb, then DisparityImageCb again.  Writes the
 //        DisparityCb cloud to <out.bin> and the second DisparityImage cloud to <out.bin>.di -- the two calibrations
 //        (stereoRectify's Q_ and the message's f, T, min_disparity) must not leak into each other
+//   d2pc_replay drop <in.raw> <w> <h> <mono8|mono16> <out.bin> [compact] [pinned]
+//        a device-side failure in mid-stream: frame 1 is published; before frame 2 the node's context is given border 0,
+//        so that the ROI outgrows the cloud DisparityCb sized for border 40 (cpp:70,72) and the ABI answers
+//        D2PC_ERR_CAPACITY -- logged, frame dropped; border 40 again, frame 3 is published and written to <out.bin>
 //   d2pc_replay latency <in.raw> <w> <h> <mono8|mono16> <frames> [compact] [pinned]
 //        per-frame wall time of DisparityCb over <frames> calls (median, p10, p90 in microseconds)
 //   d2pc_replay --gpus N | --device D [...]
@@ -177,6 +181,26 @@ int main(int argc, char **argv) {
         if (got.size() != 3) { fprintf(stderr, "expected three clouds, got %zu\n", got.size()); return 3; }
         write_cloud(argv[6], got[1]);
         write_cloud(di_out.c_str(), got[2]);
+        return 0;
+      };
+      return has_flag(argc, argv, "pinned") ? run(d2pc_shim::PinnedMsgs()) : run(d2pc_shim::Msgs());
+    }
+    if (cmd == "drop") {
+      auto run = [&](auto tag) {
+        typedef decltype(tag) M;
+        std::vector<typename M::PointCloud2> got;
+        d2pc::Disparity2PCloudT<M> node(
+            params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { got.push_back(pc); }, device_from(argc, argv), nullptr,
+            has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false, true);
+        node.DisparityCb(img);
+        if (d2pc_set_border(node.context(), 0) != D2PC_OK) return 3;
+        node.DisparityCb(img);  // D2PC_ERR_CAPACITY (PARITY) -- must neither throw nor publish
+        const size_t after_bad = got.size(), dropped = node.frames_dropped();
+        if (d2pc_set_border(node.context(), 40) != D2PC_OK) return 3;
+        node.DisparityCb(img);
+        printf("published %zu, after the failing frame %zu, dropped %zu\n", got.size(), after_bad, dropped);
+        if (got.size() != after_bad + 1 || got.empty()) { fprintf(stderr, "the frame after the failure was not published\n"); return 3; }
+        write_cloud(argv[6], got.back());
         return 0;
       };
       return has_flag(argc, argv, "pinned") ? run(d2pc_shim::PinnedMsgs()) : run(d2pc_shim::Msgs());

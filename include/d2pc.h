@@ -248,6 +248,9 @@ int d2pc_process(d2pc_ctx *ctx, const void *disp, int dtype, float scale,
  * the context's compaction state; a call on another stream gets a state buffer
  * of its own (up to 8 per context), so double-buffered use of one context on
  * two streams is safe.  The context itself is still used from one host thread.
+ * A stream handed to a COMPACT call (here and in d2pc_process_mono_device) must
+ * stay valid until the context is destroyed: the context asks it later whether
+ * the work it was given has drained, before another stream may take the buffer.
  *
  * hipGraph capture: nothing can be allocated while capturing, so a COMPACT call
  * needs its state buffer beforehand (D2PC_ERR_OUT_OF_MEMORY otherwise): run the

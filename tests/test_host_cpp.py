@@ -72,6 +72,30 @@ def test_non_colour_encoding_is_rejected_like_cv_bridge(replay, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("payload", ["pageable", "pinned"])
+@pytest.mark.parametrize("mode", ["parity", "compact"])
+def test_device_error_in_mid_stream_drops_the_frame_and_the_node_lives_on(replay, tmp_path, mode, payload):
+    """Round 4's verdict: the mirror threw out of DisparityCb on any status but OK, i.e. one transient device error killed
+    the node.  Now: logged, frame dropped (queue depth 1, hpp:78: what happens to a late frame anyway), next frame
+    published.  `d2pc_replay drop` forces D2PC_ERR_CAPACITY on the second of three frames (border 0 on the node's
+    context: the ROI outgrows the cloud sized for border 40)."""
+    import disparity_to_point_cloud_amd as d2pc
+
+    img = np.random.default_rng(3).integers(1, 256, size=(120, 200)).astype(np.uint8)
+    extra = (("compact",) if mode == "compact" else ()) + (("pinned",) if payload == "pinned" else ())
+    p, dst = _run(replay, "drop", img, "mono8", tmp_path, *extra)
+    assert p.returncode == 0, p.stderr
+    assert "published 2, after the failing frame 1, dropped 1" in p.stdout, p.stdout
+    assert "output capacity too small" in p.stderr and "frame dropped" in p.stderr
+    _, payload_bytes = dst.read_bytes().split(b"\n", 1)
+    pts = np.frombuffer(payload_bytes, dtype=np.float32).reshape(-1, 4)
+    q = d2pc.make_q_flavour()
+    med = oracle.median_u8(img, 11)
+    want = oracle.reproject(med, q, border=40, scale=0.125) if mode == "parity" else oracle.reproject_compact(med, q, border=40, scale=0.125)[0]
+    assert_points_close(pts, want, max_ulp=1, rel=1e-5, what="the frame after the dropped one")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("median", ["gpu", "hostmedian"])
 @pytest.mark.parametrize("mode", ["parity", "compact"])
 def test_c1_full_callback_640x480_mono16(replay, tmp_path, mode, median):

@@ -245,6 +245,48 @@ def test_callback_body_is_graph_capturable():
         assert_points_close(res[f][0], want, max_ulp=1, what=f"graph replay, frame {f}")
 
 
+@pytest.mark.parametrize("fused", [0, 1])
+def test_process_mono_device_compact_warm_up_then_capture_on_the_same_stream(fused):
+    """d2pc_process_mono_device in COMPACT mode, warmed up and then captured on ONE stream without d2pc_reserve_mono: the
+    two-launch form's scratch (filtered + rescaled frames) and the compaction state are the stream's own eager buffers
+    and the capture must take them over (advisor, round 4: both pools answered OUT_OF_MEMORY)."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    q = d2pc.make_q()
+    rng = np.random.default_rng(77)
+    n, h, w = 3, 300, 900
+    imgs = rng.integers(0, 65536, size=(n, h, w)).astype(np.uint16)
+    imgs[rng.random(imgs.shape) < 0.3] = 0
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        ctx.set_tuning("callback_fused_compact", 2 if fused else 0)
+        ctx.set_tuning("callback_fused", fused)
+        if fused:
+            ctx.set_tuning("median_algo", 2)   # the tile-fused kernel serves launches the bit-sliced filter takes
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True, reserve=False)
+        src = torch.from_numpy(imgs.view(np.int16)).cuda()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+
+        def body():
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_MONO16, w, h, 2 * w, 2 * w * h, n, 11, 0.125, b.points.data_ptr(),
+                                    b.index.data_ptr(), b.stride, b.counts.data_ptr(), s.cuda_stream)
+        with torch.cuda.stream(s):
+            body()
+            body()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                body()
+        b.points.fill_(0)
+        b.counts.fill_(0)
+        torch.cuda.synchronize()
+        g.replay()
+        res = b.results()
+        ctx.check_async_error()
+    for f in range(n):
+        wp, wi = oracle.reproject_compact(oracle.median_u8(oracle.mono16_to_mono8(imgs[f]), 11), q, border=40, scale=0.125)
+        assert np.array_equal(res[f][1], wi), f"frame {f}"
+        assert_points_close(res[f][0], wp, max_ulp=1, what=f"frame {f}")
+
+
 @pytest.mark.parametrize("mode", [d2pc.MODE_PARITY, d2pc.MODE_COMPACT])
 @pytest.mark.parametrize("dtype", ["u8", "mono16"])
 @pytest.mark.parametrize("chunks", [2, 0, 4])

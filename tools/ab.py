@@ -84,9 +84,10 @@ def main():
         for mode, border, pxt, bpc, nv, algo, oal, oof, form, tune in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(","), oaligns, ooffs, a.forms.split(","), a.tunes.split(";")):
             m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
             ctx = capi.Context(q=capi.make_q(), border=int(border), mode=m, compact_algo=int(algo))
-            ctx.set_tuning("pxt_parity", int(pxt))
             if mode == "compact":
                 ctx.set_tuning("pxt_compact", int(pxt))
+            else:
+                ctx.set_tuning("pxt_parity", int(pxt))   # (1, 2: one-shot blocks; 4 / 8 / 16: the tile-walking kernel, --libs exp)
             if a.small is not None:
                 ctx.set_tuning("parity_small", a.small)
             if int(form):

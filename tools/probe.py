@@ -26,6 +26,8 @@ WORKLOADS = {  # name: (mode, frames, W, H, border, hole fraction, blocky, indic
     "parity_4k_x1":       ("parity", 1, 3840, 2160, 40, 0.0, 0, False, "f32"),
     "median11_roi":       ("median", 16, 3840, 2160, 40, 0.0, 0, False, "u8"),
     "callback_u8":        ("callback", 16, 3840, 2160, 40, 0.0, 0, False, "u8"),
+    "callback_u8_compact_blocky": ("callback", 16, 3840, 2160, 40, 0.3, 1, True, "u8"),   # COMPACT + indices, 30 % zero pixels in 64 x 64 blocks
+    "callback_u8_compact_iid":    ("callback", 16, 3840, 2160, 40, 0.3, 0, True, "u8"),
 }
 
 
@@ -58,18 +60,25 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="key=value for d2pc_set_tuning (repeatable)")
     a = ap.parse_args()
     if WORKLOADS[a.workload][0] in ("median", "callback"):   # the 11 x 11 median over the inset ROI, 16 x 4K (cpp:55-57); --tune median_algo=1|2 picks the kernel
-        _, F, W, H, border, *_ = WORKLOADS[a.workload]
-        ctx = d2pc.Context(q=d2pc.make_q(), border=border)
+        _, F, W, H, border, holes, blocky, want_idx, _ = WORKLOADS[a.workload]
+        ctx = d2pc.Context(q=d2pc.make_q(), border=border, mode=d2pc.MODE_COMPACT if want_idx else d2pc.MODE_PARITY)
         for kv in a.tune:
             ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
-        raw = torch.randint(0, 256, (F, H, W), dtype=torch.uint8, device="cuda")
+        gen = torch.Generator(device="cuda").manual_seed(0xD2C)
+        raw = torch.randint(0, 256, (F, H, W), dtype=torch.uint8, device="cuda", generator=gen)
+        if holes > 0 and blocky:
+            m = torch.rand((F, (H + 63) // 64, (W + 63) // 64), device="cuda", generator=gen) < holes
+            raw[m.repeat_interleave(64, dim=1).repeat_interleave(64, dim=2)[:, :H, :W]] = 0
+        elif holes > 0:
+            raw[torch.rand(raw.shape, device="cuda", generator=gen) < holes] = 0
         dst = torch.empty_like(raw)
         s = torch.cuda.current_stream().cuda_stream
         if WORKLOADS[a.workload][0] == "callback":   # d2pc_process_mono_device: k_callback_bs<11> at this size
             from disparity_to_point_cloud_amd.torch_api import DeviceBatch as _DB
-            bb = _DB(ctx, F, H, W, dtype=torch.uint8)
+            bb = _DB(ctx, F, H, W, dtype=torch.uint8, want_index=want_idx)
             run = lambda: ctx.process_mono_device(raw.data_ptr(), d2pc.DTYPE_U8, W, H, W, W * H, F, 11, 0.125,
-                                                  bb.points.data_ptr(), None, bb.stride, bb.counts.data_ptr(), s)
+                                                  bb.points.data_ptr(), bb.index.data_ptr() if want_idx else None, bb.stride,
+                                                  bb.counts.data_ptr(), s)
         else:
             run = lambda: ctx.median_roi_device(raw.data_ptr(), W, H, W, W * H, F, dst.data_ptr(), W, W * H, 11, s)
         run(); torch.cuda.synchronize()
