@@ -278,22 +278,19 @@ def compaction_counters(ctx):
             "twopass_fallbacks": st["twopass_fallbacks"]}
 
 
-def valu_issue(kernel_ms, key):
+def valu_issue(key):
     """The callback-body kernels are bound by VALU issue, not by HBM: next to their HBM fraction the line carries the
     fraction of the chip's vector-issue slots they fill = VALU wave-instructions x 2 cycles (a wave64 instruction occupies
     its SIMD-32 for two; fp64 and a few integer forms take four, so this is a LOWER bound of the slots really taken)
-    / (1,024 SIMDs x cycles of the launch at the clock the counter pass measured).  The instruction count per launch is
-    COPIED from the tracked counter passes (profiles/valu_issue.json, separate rocprofv3 --pmc runs of this build's
-    kernels), the time is this run's."""
+    / (1,024 SIMDs x the launch's cycles).  COPIED from the tracked counter passes (profiles/valu_issue.json: separate
+    rocprofv3 --pmc runs of these kernels; cycles per launch do not move with the clock), not measured by this run."""
     prof = os.path.join(ROOT, "profiles", "valu_issue.json")
     try:
         t = json.load(open(prof))[key]
     except Exception:
         return {}
-    cycles = kernel_ms * 1e-3 * t["clock_ghz"] * 1e9 * 1024
-    return {"valu_issue_frac": round(t["valu_wave_insts_per_launch"] * 2 / cycles, 4),
-            "valu_wave_insts_per_launch": t["valu_wave_insts_per_launch"], "valu_issue_clock_ghz": t["clock_ghz"],
-            "valu_issue_source": t.get("source"), "valu_issue_profile_build": t.get("build")}
+    return {"valu_issue_frac": t["valu_issue_frac"], "simd_cycles_per_valu_wave_instruction": t["simd_cycles_per_valu_wave_instruction"],
+            "valu_issue_measured": False, "valu_issue_source": t.get("source")}
 
 
 def cpu_baseline(q, border, budget_s=12.0):
@@ -684,7 +681,7 @@ def main():
         variants["callback_u8_median11_parity_border40"] = {
             "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
             "achieved_GBs": round(ab_cb / (kms * 1e-3) / 1e9, 1), "frac": round(ab_cb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            **valu_issue(kms, "callback_parity"),
+            **valu_issue("callback_parity"),
             "kernel_ms_spread": sp, "as_two_launches_ms_spread": sp2,
             "what": "d2pc_process_mono_device: k_callback_bs<11> (bit-sliced median of a tile + its points from LDS) per step",
             "as_two_launches_ms": round(kms2, 4),
@@ -732,7 +729,7 @@ def main():
             variants[f"callback_u8_median11_compact_30pct_zero_{hole_kind}"] = {
                 "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
                 "achieved_GBs": round(ab_cc / (kms * 1e-3) / 1e9, 1), "frac": round(ab_cc / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                **valu_issue(kms, "callback_compact_" + hole_kind),
+                **valu_issue("callback_compact_" + hole_kind),
                 "kernel_ms_spread": rec[2][0], "points_per_step": npts, "compaction_counters": rec[2][1],
                 "what": "d2pc_process_mono_device, COMPACT + indices: k_callback_bs_compact_pipe<11> (persistent blocks: median of "
                         "a tile, then the previous tile's surviving points in row-major order; row counts handed over inside the launch)",
@@ -765,6 +762,8 @@ def main():
         r["callback_parity_frac"] = variants["callback_u8_median11_parity_border40"]["frac"]
         r["callback_compact_ms"] = variants["callback_u8_median11_compact_30pct_zero_blocky"]["kernel_ms_avg"]
         r["callback_compact_frac"] = variants["callback_u8_median11_compact_30pct_zero_blocky"]["frac"]
+        r["callback_parity_valu_issue_frac"] = variants["callback_u8_median11_parity_border40"].get("valu_issue_frac")
+        r["callback_compact_valu_issue_frac"] = variants["callback_u8_median11_compact_30pct_zero_blocky"].get("valu_issue_frac")
     if rank == 0 and world == 1 and not a.no_cpu:  # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(q, a.border)
     if rank == 0:

@@ -53,6 +53,20 @@ def derive(m, probe):
                   "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA"):
             if g(c) is not None and c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
                 d[c + "/SQ_WAVE_CYCLES"] = g(c) / g("SQ_WAVE_CYCLES")
+    if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (4 for fp64
+        # and a few integer forms): the fraction below is therefore a LOWER bound of the vector-issue slots taken
+        cyc = g("GRBM_GUI_ACTIVE") / 8.0
+        d["gpu_cycles_per_launch(GRBM_GUI_ACTIVE/8)"] = cyc
+        d["valu_issue_frac(SQ_INSTS_VALU x 2 cycles / 1024 SIMDs / cycles)"] = g("SQ_INSTS_VALU") * 2.0 / 1024.0 / cyc
+        d["simd_cycles_per_valu_wave_instruction"] = 1024.0 * cyc / g("SQ_INSTS_VALU")
+        if g("duration_us_under_pmc_mean"):
+            d["effective_clock_ghz_under_pmc"] = cyc / g("duration_us_under_pmc_mean") / 1e3
+        if g("SQ_LDS_IDX_ACTIVE") is not None:
+            d["lds_array_busy_frac(SQ_LDS_IDX_ACTIVE / 256 CUs / cycles)"] = g("SQ_LDS_IDX_ACTIVE") / 256.0 / cyc
+            d["lds_bank_conflict_frac_of_lds_cycles"] = g("SQ_LDS_BANK_CONFLICT", 0.0) / max(g("SQ_LDS_IDX_ACTIVE"), 1.0)
+        if g("SQ_WAVE_CYCLES"):
+            d["waves_resident_per_cu(SQ_WAVE_CYCLES x 4 / cycles / 256)"] = g("SQ_WAVE_CYCLES") * 4.0 / cyc / 256.0
     if probe and g("SQ_INSTS_VMEM_WR"):
         px = probe["roi_pixels"]
         d["pixels_per_launch"] = px
