@@ -1179,7 +1179,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "callback_fused_compact") && value >= 0 && value <= 2) ctx->cb_fused_compact = value;
   else if (!strcmp(key, "callback_pipe_blocks_per_cu") && value >= 1 && value <= 8) ctx->cb_pipe_blocks_per_cu = value;
   else if (!strcmp(key, "host_direct_read") && (value == 0 || value == 1)) ctx->host_direct_read = value;
-  else if (!strcmp(key, "median_algo") && value >= 0 && value <= 2) ctx->median_algo = value;
+  else if (!strcmp(key, "median_algo") && value >= 0 && value <= (D2PC_EXPERIMENTS ? 3 : 2)) ctx->median_algo = value;
   else if (!strcmp(key, "fuse_rows") && (value == 0 || (value >= 2 && value <= 1024))) ctx->fuse_rows = value;
   else if (!strcmp(key, "membench_blocks_per_cu") && value >= 0 && value <= 256) ctx->membench_blocks_per_cu = value;
   else if (!strcmp(key, "membench_unroll") && (value == 1 || value == 2 || value == 4)) ctx->membench_unroll = value;

@@ -136,7 +136,7 @@ constexpr uint64_t bs_min_tiles(int ksize) { return ksize <= 3 ? 192 : ksize <= 
 
 bool median_uses_bs(const MedianArgs &a, int ksize) {
   return median_ksize_supported(ksize) && a.out_w != 0 && a.out_h != 0 &&
-         (a.algo == 2 || (a.algo == 0 && median_bs_tiles(a) >= bs_min_tiles(ksize)));
+         (a.algo == 2 || a.algo == 3 || (a.algo == 0 && median_bs_tiles(a) >= bs_min_tiles(ksize)));  // (3: experiment build, the lane-pair select)
 }
 
 hipError_t launch_median(const void *src, void *dst, const MedianArgs &args, int ksize, hipStream_t stream) {

@@ -220,6 +220,79 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
   }
 }
 
+
+#if D2PC_EXPERIMENTS
+// ---- EXPERIMENT (round 4's verdict, item 3c; experiment build only): the candidate window split over a LANE PAIR -------
+// The select above keeps k*k candidate words per thread (121 at 11 x 11): 159 VGPRs, three waves per SIMD -- the worst
+// occupancy for two-cycle instructions (profiles/r02_valu_rates.txt: 3.03 cycles per instruction at 3 waves, 2.75 at 2, 2.68
+// at 4) and too few waves to cover the waits (4.0 SIMD-cycles per instruction measured, profiles/r05_callback_counters.json).
+// Here two adjacent lanes (h = lane & 1) serve ONE (t, row): lane h owns the window rows dy = r + (KS / 2) h, r = 0 .. KS / 2
+// -- the middle row is shared, by columns: h = 0 owns its columns 0 .. KS / 2, h = 1 the rest; the words a lane does not own
+// start as "no candidate" and never count.  Each lane sums its own candidates with the same carry-save tree, the two 8-digit
+// sums are exchanged (8 DPP quad_perm moves) and added bit-sliced (15 v_bitop3), so both lanes know the median's bit and the
+// new rank and update their own half.  (KS / 2 + 1) * KS candidate words per lane (66 at 11 x 11) -> four waves per SIMD;
+// ~+20 % instructions per pixel (the shared row's unowned words, the exchange, the rank seed's mask).
+template <int KS, int PAR>
+__device__ __forceinline__ void select2(const uint32_t *__restrict__ w_row, uint32_t *__restrict__ bits_out, const uint32_t h) {
+  using S = MedianBsShape<KS>;
+  constexpr int NWORD = 2 * S::NREAD, HR = KS / 2 + 1;  // local rows per lane
+  const uint32_t own0 = h ? 0u : 0xffffffffu, own1 = ~own0;  // all ones in the lanes of half 0 / half 1
+  uint32_t cand[HR][KS];
+#pragma unroll
+  for (int r = 0; r < HR; ++r)
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) {
+      // half 0: local row HR-1 is the shared row dy = KS/2, it owns columns 0 .. KS/2; half 1: local row 0 is the shared row, columns KS/2+1 ..
+      uint32_t v = 0xffffffffu;
+      if (r == HR - 1 && dx > KS / 2) v = own1;       // (half 0 does not own these; for half 1 this is its last row dy = KS-1: owned)
+      if (r == 0 && dx <= KS / 2) v = own0;           // (half 1 does not own these; for half 0 this is dy = 0: owned)
+      cand[r][dx] = v;
+    }
+  uint32_t mm[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) mm[k] = ((127 - S::D0) >> k) & 1 ? 0xffffffffu : 0u;
+#pragma unroll 1
+  for (int pl = 7; pl >= 0; --pl) {
+    const uint32_t *wp = w_row + pl * S::PLANE_STRIDE;
+    Csa c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.a[k] = k < 7 ? (mm[k] & own0) : 0u, c.b[k] = 0u, c.n[k] = k < 7 ? 1 : 0;  // the rank seed counts once: in half 0
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+      uint32_t w[NWORD];
+      ld_row<KS>(wp + r * S::ROW_STRIDE, w);
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, cand[r][dx] & w[dx + PAR]);
+    }
+    uint32_t mine[8], s[8];
+    csa_finish(c, mine);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // own + partner's sum, digit by digit (both lanes of the pair form the same total)
+      const uint32_t other = uint32_t(__builtin_amdgcn_update_dpp(0, int(mine[k]), 0xB1, 0xf, 0xf, false));  // quad_perm:[1,0,3,2]
+      if (k == 0) {
+        s[0] = mine[0] ^ other, carry = mine[0] & other;
+      } else {
+        s[k] = bitop3<0x96>(mine[k], other, carry);
+        if (k < 7) carry = bitop3<0xe8>(mine[k], other, carry);
+      }
+    }
+    if (h == 0) bits_out[pl * 256] = s[7];
+    if (pl == 0) break;
+    const uint32_t is0 = ~s[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) mm[k] = bitop3<0xca>(is0, s[k], mm[k]);
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+      uint32_t w[NWORD];
+      ld_row<KS>(wp + r * S::ROW_STRIDE, w);
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) cand[r][dx] = bitop3<0x48>(w[dx + PAR], cand[r][dx], is0);
+    }
+  }
+}
+#endif  // D2PC_EXPERIMENTS
+
 }  // namespace bs
 
 // Stage 1a of one 256 x 32 tile whose first output pixel is (x0, y0) of frame `fsrc`: the tile's input rows (+ halo),
@@ -347,5 +420,99 @@ __device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows
   }
   __syncthreads();
 }
+
+#if D2PC_EXPERIMENTS
+// The tile body around select2: the same four stages with 512 threads per 256 x 32 tile (two lanes per (t, row)).
+// Experiment build only (k_median_bs2_u8, median_algo 3).
+template <int KS>
+__device__ __forceinline__ void median_bs2_tile(const uint8_t *__restrict__ fsrc, const MedianArgs &a, const int x0, const int y0,
+                                                uint32_t (&s_w)[MedianBsShape<KS>::W_WORDS],
+                                                uint32_t (&s_raw)[MedianBsShape<KS>::RAW_WORDS], const uint32_t tid) {
+  using S = MedianBsShape<KS>;
+  constexpr int NT = 512, R = S::R, RUNS = S::RAW_STRIDE / 16, TOTAL = S::IN_ROWS * RUNS, PER = (TOTAL + NT - 1) / NT;
+  // ---- 1. input rows (+ halo), replicated at the image edges, as 16-byte runs: all loads first
+  uint4 v[PER];
+  const bool interior = x0 - R >= 0 && x0 - R + S::RAW_STRIDE <= int(a.width);
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t c = tid + uint32_t(k * NT);
+    const uint32_t r = c / uint32_t(RUNS), i16 = 16u * (c - r * uint32_t(RUNS));
+    int iy = y0 - R + int(r);
+    iy = iy < 0 ? 0 : iy >= int(a.height) ? int(a.height) - 1 : iy;
+    const uint8_t *row = fsrc + uint64_t(iy) * a.src_row_stride;
+    const int x = x0 - R + int(i16);
+    if (interior) {
+      __builtin_memcpy(&v[k], row + x, 16);
+    } else {
+      uint32_t d[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        d[q] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int ix = x + 4 * q + e;
+          ix = ix < 0 ? 0 : ix >= int(a.width) ? int(a.width) - 1 : ix;
+          d[q] |= uint32_t(row[ix]) << (8 * e);
+        }
+      }
+      v[k] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t c = tid + uint32_t(k * NT);
+    if (c < uint32_t(TOTAL)) reinterpret_cast<uint4 *>(s_raw)[c] = v[k];
+  }
+  __syncthreads();
+  // ---- 2. plane words (as in median_bs_tile_from)
+  {
+    const uint8_t *raw = reinterpret_cast<const uint8_t *>(s_raw);
+    for (uint32_t item = tid; item < uint32_t(S::IN_ROWS * S::S); item += uint32_t(NT)) {
+      const uint32_t r = item >> 3, u = item & 7u;
+      const uint8_t *rp = raw + r * uint32_t(S::RAW_STRIDE) + u;
+      uint32_t px[8], plane[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        px[k] = uint32_t(rp[32 * k]) | (uint32_t(rp[32 * k + 8]) << 8) | (uint32_t(rp[32 * k + 16]) << 16) |
+                (uint32_t(rp[32 * k + 24]) << 24);
+      const uint32_t e1 = rp[256], e2 = rp[264];
+      bs::to_planes(px, plane);
+      uint32_t *wr = s_w + r * uint32_t(S::ROW_STRIDE) + u;
+#pragma unroll
+      for (int pl = 0; pl < 8; ++pl) {
+        const uint32_t hi = ((e1 >> pl) & 1u) | (((e2 >> pl) & 1u) << 1);
+        wr[pl * S::PLANE_STRIDE] = plane[pl];
+        if (u + 8u < uint32_t(S::NW)) wr[pl * S::PLANE_STRIDE + 8] = __builtin_amdgcn_alignbit(hi, plane[pl], 1);
+        if (S::NW > 16 && u + 16u < uint32_t(S::NW)) wr[pl * S::PLANE_STRIDE + 16] = __builtin_amdgcn_alignbit(hi, plane[pl], 2);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. the select: wave = one parity of t, 8 rows; lane = h + 2 * ((t >> 1) + 4 * row)
+  {
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const uint32_t par = wave & 1u, h = lane & 1u, t = 2u * ((lane >> 1) & 3u) + par, row = 8u * (wave >> 1) + (lane >> 3);
+    const uint32_t *w_row = s_w + (row + uint32_t(KS / 2) * h) * uint32_t(S::ROW_STRIDE) + (t - par);
+    uint32_t *bits_out = s_raw + (row * 8u + t);  // logical thread (t, row); 8 plane words 256 apart
+    if (par) bs::select2<KS, 1>(w_row, bits_out, h);
+    else bs::select2<KS, 0>(w_row, bits_out, h);
+  }
+  __syncthreads();
+  // ---- 4. bit planes -> bytes, staged in W's space (the first 256 threads: one per (t, row))
+  if (tid < 256u) {
+    const uint32_t row = tid >> 3, t = tid & 7u;
+    uint32_t plane[8], px[8];
+#pragma unroll
+    for (int pl = 0; pl < 8; ++pl) plane[pl] = s_raw[pl * 256 + tid];
+    bs::to_pixels(plane, px);
+    uint8_t *ob = reinterpret_cast<uint8_t *>(s_w) + row * uint32_t(S::OUT_STRIDE) + t;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ob[8 * (4 * k + q)] = uint8_t(px[k] >> (8 * q));
+  }
+  __syncthreads();
+}
+#endif  // D2PC_EXPERIMENTS
 
 }  // namespace d2pc
