@@ -337,6 +337,32 @@ def cpu_baseline(q, border, budget_s=12.0):
     }
 
 
+def cpu_callback_body(q, border, frames=3):
+    """The WHOLE callback body on the CPU (cpp:55-85: median 11 -> x 1/8 -> reproject + pack), the oracle's restatement, one
+    thread, a bounded sample of 8-bit 4K frames: the CPU column beside the callback_* lines (round 4's verdict, missing #5).
+    NOT a fair stand-in for the reference's cost: oracle/d2pc_oracle.c's median recounts a k x k histogram walk per pixel
+    (clarity over speed), while cv::medianBlur uses the constant-time sliding-histogram algorithm with SIMD for 8-bit images
+    and k > 5 [upstream] -- expect OpenCV's filter several times faster than this port; the reprojection part is the same
+    loop cpu_baseline times."""
+    import oracle
+
+    rng = np.random.default_rng(0xD2C)
+    img = rng.integers(0, 256, size=(H4K, W4K)).astype(np.uint8)
+    oracle.reproject(oracle.median_u8(img[:256], 11), q, border=border, scale=0.125)  # warm
+    t0 = time.perf_counter()
+    tm = 0.0
+    for _ in range(frames):
+        t1 = time.perf_counter()
+        med = oracle.median_u8(img, 11)
+        tm += time.perf_counter() - t1
+        oracle.reproject(med, q, border=border, scale=0.125, threads=1)
+    el = time.perf_counter() - t0
+    return {"value": round(W4K * H4K * frames / el / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "median_share_of_time": round(tm / el, 3),
+            "sample": f"{frames} frames of 3840x2160 u8: oracle median 11 x 11 (per-pixel histogram walk: slower than cv::medianBlur's "
+                      f"constant-time algorithm, so this UNDERSTATES the reference) + x 1/8 + reproject, {el:.1f} s"}
+
+
 def host_path_rates(q, border):
     """PCIe-inclusive rates of the host entry points for one 4K fp32 frame (never the headline): the
     synchronous d2pc_process on pageable buffers, and the pipelined path (depth 3, pinned staging,
@@ -766,6 +792,10 @@ def main():
         r["callback_compact_valu_issue_frac"] = variants["callback_u8_median11_compact_30pct_zero_blocky"].get("valu_issue_frac")
     if rank == 0 and world == 1 and not a.no_cpu:  # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(q, a.border)
+        if "variants_1gpu" in out:  # the CPU column of the callback-body lines
+            cb = cpu_callback_body(q, a.border)
+            out["cpu_baseline"]["callback_body"] = cb
+            out["roofline"]["callback_cpu_port_Mpix_s"] = cb["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     multi_gpu.barrier()

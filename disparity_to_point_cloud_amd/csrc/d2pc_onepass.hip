@@ -193,6 +193,9 @@ __device__ __forceinline__ void run_scatter_dense(const QArg<QK> &Q, const Geom 
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     if (uint32_t(s) * 64u >= c) break;  // (wave-uniform)
+    // (starting every store instruction on a 64-byte line of the output -- the run's first pos0 & 3 lanes idle, 16 whole
+    // lines per instruction instead of 17 partial ones -- changes nothing: L2 merges the shared end lines of plain stores;
+    // profiles/r05_ab_dense_variants.txt)
     const uint32_t j = uint32_t(s) * 64u + lane;
     const float d = run[j];       // (lanes past c read what the pack left there: computed, never stored)
     const uint32_t o = off[j];
