@@ -349,15 +349,23 @@ def cpu_callback_body(q, border, frames=3):
     rng = np.random.default_rng(0xD2C)
     img = rng.integers(0, 256, size=(H4K, W4K)).astype(np.uint8)
     oracle.reproject(oracle.median_u8(img[:256], 11), q, border=border, scale=0.125)  # warm
-    t0 = time.perf_counter()
-    tm = 0.0
-    for _ in range(frames):
-        t1 = time.perf_counter()
-        med = oracle.median_u8(img, 11)
-        tm += time.perf_counter() - t1
-        oracle.reproject(med, q, border=border, scale=0.125, threads=1)
-    el = time.perf_counter() - t0
-    return {"value": round(W4K * H4K * frames / el / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+    # the oracle's median is an OpenMP loop over rows: ONE thread here, like the reference's single-threaded spinner
+    try:
+        from threadpoolctl import threadpool_limits
+        limit, cores = threadpool_limits(limits=1, user_api="openmp"), 1
+    except Exception:
+        import contextlib
+        limit, cores = contextlib.nullcontext(), oracle.max_threads()
+    with limit:
+        t0 = time.perf_counter()
+        tm = 0.0
+        for _ in range(frames):
+            t1 = time.perf_counter()
+            med = oracle.median_u8(img, 11)
+            tm += time.perf_counter() - t1
+            oracle.reproject(med, q, border=border, scale=0.125, threads=1)
+        el = time.perf_counter() - t0
+    return {"value": round(W4K * H4K * frames / el / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "median_share_of_time": round(tm / el, 3),
             "sample": f"{frames} frames of 3840x2160 u8: oracle median 11 x 11 (per-pixel histogram walk: slower than cv::medianBlur's "
                       f"constant-time algorithm, so this UNDERSTATES the reference) + x 1/8 + reproject, {el:.1f} s"}

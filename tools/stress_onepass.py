@@ -30,6 +30,7 @@ while done < launches:
     if rng.random() < 0.2: w, h = 3840, 2160; n = min(n, 16)
     border = int(rng.choice([0, 8, 40]))
     if w <= 2 * border or h <= 2 * border: continue
+    form = int(rng.choice([0, 0, 0, 2, 1, 3, 4]))   # the single pass's kernel form (0 / 2: the product's dense pass)
     pxt = int(rng.choice([4, 8, 16])); opbpc = int(rng.choice([1, 2, 3, 4, 6, 8])); idx = bool(rng.integers(0, 2))
     holes = float(rng.choice([0.0, 0.02, 0.3, 0.7, 0.98]))
     disp = torch.rand((n, h, w), generator=g, device="cuda") * 127.5 + 0.5
@@ -44,6 +45,7 @@ while done < launches:
     for algo in (1, 2):
         with d2pc.Context(q=q, border=border, mode=d2pc.MODE_COMPACT, compact_algo=algo) as ctx:
             ctx.set_tuning("pxt_compact", pxt); ctx.set_tuning("onepass_blocks_per_cu", opbpc)
+            if algo == 2: ctx.set_tuning("onepass_form", form)
             b = DeviceBatch(ctx, n, h, w, want_index=idx)
             b.points.fill_(-7.0)
             if idx: b.index.fill_(-7)
@@ -57,7 +59,7 @@ while done < launches:
             torch.cuda.synchronize()
             ctx.check_async_error()
             outs.append((b.counts.clone(), b.points.clone(), b.index.clone() if idx else None))
-    what = f"launch {done}: n={n} {w}x{h} b={border} pxt={pxt} opbpc={opbpc} idx={idx} holes={holes} kind={kind}"
+    what = f"launch {done}: form={form} n={n} {w}x{h} b={border} pxt={pxt} opbpc={opbpc} idx={idx} holes={holes} kind={kind}"
     assert torch.equal(outs[0][0], outs[1][0]), what + " counts differ"
     # compare the first count[f] points of every frame (the rest of each frame's slab is untouched: -7)
     assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32)), what + " points differ"
