@@ -28,12 +28,16 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
   __shared__ __attribute__((aligned(16))) uint32_t s_w[S::W_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t s_raw[S::RAW_WORDS];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef D2PC_DIAG
+  const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   uint32_t b = blockIdx.x;
   const uint32_t f = b / (ma.tiles_x * ma.tiles_y);
   b -= f * ma.tiles_x * ma.tiles_y;
   const uint32_t ty = b / ma.tiles_x, tx = b - ty * ma.tiles_x;
   const uint32_t x0 = ma.out_x0 + tx * uint32_t(S::TW), y0 = ma.out_y0 + ty * uint32_t(S::TH);  // first output pixel
   median_bs_tile<KS>(src + uint64_t(f) * ma.src_frame_stride, ma, int(x0), int(y0), s_w, s_raw, tid);
+  D2PC_BS_STAMP(e0);
 
   double *lut_iw = reinterpret_cast<double *>(s_raw);              // [256]
   float *lut_z = reinterpret_cast<float *>(s_raw) + 2 * 256;       // [256]
@@ -57,10 +61,12 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
     xs[q] = 0.0;
     if constexpr (is_stereo(QK)) xs[q] = stereo_nx(Q, x0 + 64u * uint32_t(q) + lane);
   }
+  const uint32_t r_end = y_end - y0 < uint32_t(S::TH) ? y_end - y0 : uint32_t(S::TH);  // rows of the tile inside the ROI
+  // (two or four rows per trip, so that their chains LDS byte -> table entry -> fp64 products -> store overlap: no difference,
+  // 578.9 / 578.8 / 579.4 us per 16 x 4K; the epilogue is 13 % of a block's cycles and store-issue-bound: profiles/r05_callback_phases.txt)
 #pragma unroll 1
-  for (uint32_t r = wave; r < uint32_t(S::TH); r += uint32_t(S::THREADS / 64)) {  // a wave takes every fourth row
+  for (uint32_t r = wave; r < r_end; r += uint32_t(S::THREADS / 64)) {  // a wave takes every fourth row
     const uint32_t y = y0 + r;
-    if (y >= y_end) break;
     const uint32_t row_point = (y - g.border) * g.roi_w - g.border;  // + x = the point's index (wraps for x < border: never used)
     uint32_t raw[4];
 #pragma unroll
@@ -86,6 +92,15 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
     }
   }
   if (counts && b == 0 && tid == 0) counts[f] = g.roi_n;
+#ifdef D2PC_DIAG
+  {
+    const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+    D2PC_BS_ADD(0, 1);
+    D2PC_BS_ADD(5, e1 - e0);
+    D2PC_BS_ADD(6, e1 - diag_t0);
+    if (tid == 0) atomicAdd(&g_bs_diag[blockIdx.x & 255u][14], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - diag_r0));
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------
@@ -726,3 +741,19 @@ hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const v
 
 
 }  // namespace d2pc
+
+#ifdef D2PC_DIAG
+// diagnostic build only (tools/diag_callback.py): read and reset the stage timers of the tile body
+extern "C" int d2pc_debug_read_bs_diag(unsigned long long *out16) {
+  static unsigned long long all[256][16];
+  if (hipMemcpyFromSymbol(all, HIP_SYMBOL(d2pc::g_bs_diag), sizeof all) != hipSuccess) return 6;
+  for (int i = 0; i < 16; ++i) {
+    out16[i] = 0;
+    for (int s = 0; s < 256; ++s) out16[i] += all[s][i];
+  }
+  for (auto &row : all)
+    for (auto &x : row) x = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(d2pc::g_bs_diag), all, sizeof all) != hipSuccess) return 6;
+  return 0;
+}
+#endif

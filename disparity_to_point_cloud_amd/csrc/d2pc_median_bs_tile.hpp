@@ -35,6 +35,21 @@
 
 namespace d2pc {
 
+#ifdef D2PC_DIAG
+// diagnostic build: shader-clock sums per stage of the tile body, added by wave 0's lane 0 of every block
+// (tools/diag_callback.py): [0] tiles, [1] rows requested -> staged in LDS, [2] plane words, [3] select, [4] bytes back,
+// [5] the caller's epilogue, [6] block lifetime, [7] the same in 100 MHz ticks; [8..13] the same stamps for the block's LAST wave
+// (256 slots of 16 words, one 128-byte line each, picked by the block index: thousands of blocks adding to ONE word serialise at
+// the memory side and tripled the kernel's time in the first form of this diagnostic)
+inline __device__ unsigned long long g_bs_diag[256][16];
+#define D2PC_BS_STAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#define D2PC_BS_ADD(i, v) \
+  do { if ((tid & 63u) == 0u && ((tid >> 6) == 0u || (tid >> 6) == 3u)) atomicAdd(&g_bs_diag[blockIdx.x & 255u][(i) + ((tid >> 6) == 3u ? 7 : 0)], (unsigned long long)(v)); } while (0)
+#else
+#define D2PC_BS_STAMP(x)
+#define D2PC_BS_ADD(i, v)
+#endif
+
 template <int KS>
 struct MedianBsShape {
   static constexpr int R = KS / 2;
@@ -363,12 +378,14 @@ __device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows
                                                     uint32_t (&s_raw)[MedianBsShape<KS>::RAW_WORDS], const uint32_t tid) {
   using S = MedianBsShape<KS>;
   using RW = MedianBsRows<KS>;
+  D2PC_BS_STAMP(d0);
 #pragma unroll
   for (int k = 0; k < RW::PER_THREAD; ++k) {
     const uint32_t c = tid + uint32_t(k * S::THREADS);
     if (c < uint32_t(RW::TOTAL)) reinterpret_cast<uint4 *>(s_raw)[c] = rows.v[k];
   }
   __syncthreads();
+  D2PC_BS_STAMP(d1);
 
   // ---- 2. plane words: item (row r, u) gathers the pixels 8 j + u of the row --------------------------
   {
@@ -394,6 +411,7 @@ __device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows
     }
   }
   __syncthreads();
+  D2PC_BS_STAMP(d2);
 
   // ---- 3. the select: wave = one parity of t, 16 rows; lane = (t >> 1) + 4 * row -----------------------
   const uint32_t wave = tid >> 6, lane = tid & 63u;
@@ -405,6 +423,7 @@ __device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows
     else bs::select<KS, 0>(w_row, bits_out);
   }
   __syncthreads();  // every wave has finished reading W
+  D2PC_BS_STAMP(d3);
 
   // ---- 4. bit planes -> bytes, staged in W's space, stored in 16-byte runs ---------------------------
   {
@@ -419,6 +438,11 @@ __device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows
       for (int q = 0; q < 4; ++q) ob[8 * (4 * k + q)] = uint8_t(px[k] >> (8 * q));
   }
   __syncthreads();
+  D2PC_BS_STAMP(d4);
+  D2PC_BS_ADD(1, d1 - d0);
+  D2PC_BS_ADD(2, d2 - d1);
+  D2PC_BS_ADD(3, d3 - d2);
+  D2PC_BS_ADD(4, d4 - d3);
 }
 
 #if D2PC_EXPERIMENTS
