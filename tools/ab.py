@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--opbpc", type=int, default=4, help="single-pass kernel: persistent blocks per CU")
     ap.add_argument("--oaligns", default="16", help="output frame stride rounded up to this many points (several: A/B)")
     ap.add_argument("--ooffs", default="0", help="output base offset in points (several: A/B)")
+    ap.add_argument("--ioffs", default="0", help="index base offset in 4-byte elements (several: A/B) -- does the relation of the index stream's addresses to the point stream's matter?")
     ap.add_argument("--small", type=int, default=None, help="tuning parity_small (1: one-shot blocks also for pxt 4)")
     ap.add_argument("--forms", default="0", help="tuning reproject_form (0 per Q kind, 24 / 4: one OpenCV generation bit for bit)")
     ap.add_argument("--tunes", default="", help="alternatives separated by ';', each a comma-separated list of d2pc_set_tuning key=value (e.g. 'chunk_mb=96;chunk_mb=48,chunk_first_frames=1')")
@@ -65,23 +66,25 @@ def main():
     ooffs = [int(x) for x in a.ooffs.split(",")]
     max_stride = max((W * H + al - 1) // al * al for al in oaligns)
     pool = torch.empty((F * max_stride + max(ooffs) + 16, 4), dtype=torch.float32, device="cuda")
-    index = torch.empty((F, max_stride), dtype=torch.int32, device="cuda") if a.idx else None
+    ioffs = [int(x) for x in a.ioffs.split(",")]
+    index = torch.empty((F * max_stride + max(ioffs) + 64,), dtype=torch.int32, device="cuda") if a.idx else None
     counts = torch.zeros((F,), dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     class Cand:
-        def __init__(self, ctx, oalign, ooff):
+        def __init__(self, ctx, oalign, ooff, ioff=0):
             self.ctx = ctx
             self.stride = (W * H + oalign - 1) // oalign * oalign
             self.out_ptr = pool.data_ptr() + 16 * ooff
+            self.idx_ptr = index.data_ptr() + 4 * ioff if index is not None else None
             ctx.reserve(W, H, F)
         def launch(self):
             self.ctx.process_device(disp.data_ptr(), dcode, dscale, W, H, W * esize, W * H * esize, F, self.out_ptr,
-                                    index.data_ptr() if index is not None else None, self.stride, counts.data_ptr(), stream)
+                                    self.idx_ptr, self.stride, counts.data_ptr(), stream)
 
     for lib in a.libs.split(","):
         L = load_variant(lib)
-        for mode, border, pxt, bpc, nv, algo, oal, oof, form, tune in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(","), oaligns, ooffs, a.forms.split(","), a.tunes.split(";")):
+        for mode, border, pxt, bpc, nv, algo, oal, oof, form, tune, iof in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(","), oaligns, ooffs, a.forms.split(","), a.tunes.split(";"), ioffs):
             m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
             ctx = capi.Context(q=capi.make_q(), border=int(border), mode=m, compact_algo=int(algo))
             if mode == "compact":
@@ -97,12 +100,12 @@ def main():
             for kv in filter(None, tune.split(",")):
                 k, v = kv.split("=")
                 ctx.set_tuning(k, int(v))
-            b = Cand(ctx, oal, oof)
+            b = Cand(ctx, oal, oof, iof)
             b.launch(); torch.cuda.synchronize()
             npts = int(counts.sum().item())
             roi_n = capi.roi_points(W, H, int(border))
             alg = esize * F * roi_n + (20 if a.idx else 16) * npts
-            cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo} oalign={oal} ooff={oof} form={form} {tune}", b, alg, []))
+            cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo} oalign={oal} ooff={oof} form={form} {tune}" + (f" ioff={iof}" if len(ioffs) > 1 else ""), b, alg, []))
     for r in range(a.rounds):
         for label, b, alg, ts in cands:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
