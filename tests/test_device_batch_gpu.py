@@ -165,6 +165,36 @@ def test_single_pass_dense_forms_at_4k(form):
         assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"4K compact frame {f}")
 
 
+def test_single_pass_self_cleaning_state_survives_other_uses_of_the_buffer():
+    """The dense single pass zeroes the idle half of its state buffer for its successor (no clear kernel in front of eager
+    launches).  ONE context, ONE stream, the default routing: big batches (single pass) relaunched, interleaved with a
+    camera-size launch (resident blocks: epochs in the same buffer), a mid-size one (two-pass: its partial counts land in
+    the same buffer) and a big batch of ANOTHER frame count (other half size) -- whatever ran last, the next single-pass
+    launch must find clean state or clear it: every cloud against the oracle."""
+    q = d2pc.make_q()
+    kinds = ["holes", "blocky", "uniform"]
+    pool = [synth_disparity(3, 400 + f, 1920, 1080, kinds[f % 3]) for f in range(30)]
+    want = [oracle.reproject_compact(fr, q, border=40) for fr in pool]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        batches = {n: _batch(ctx, pool[:n], want_index=True, reserve=False) for n in (30, 24, 12, 2)}
+        ctx.compact_stats_reset()
+        seq = [30, 30, 2, 30, 12, 30, 24, 24, 30, 2, 24]   # (12 x 1080p: too many blocks to be resident, too few tiles for the single pass)
+        for step, n in enumerate(seq):
+            b = batches[n]
+            b.points.fill_(0)
+            b.index.fill_(0)
+            b.counts.fill_(0)
+            b.launch()
+            res = b.results()
+            ctx.check_async_error()
+            for f, (pts, idx) in enumerate(res):
+                assert np.array_equal(idx, want[f][1]), f"step {step} (n = {n}) frame {f}"
+                assert_points_close(pts, want[f][0], max_ulp=1, what=f"step {step} (n = {n}) frame {f}")
+        st = ctx.compact_stats()
+        # eight single-pass launches (n = 30, 24) and two resident ones (n = 2); the two-pass form (n = 12) hands nothing over
+        assert st["launches"] == 10 and st["timeouts"] == 0, st
+
+
 @pytest.mark.parametrize("big_batch_algo", [2, 4])
 def test_default_algorithm_on_a_large_batch(big_batch_algo):
     """compact_algo = 0 picks the big-batch form -- the single pass -- for big launches (>= 4 frames, >= 20,480 tiles):
