@@ -20,7 +20,7 @@
 
 namespace d2pc {
 // --------------------------------------------------------------------------
-// K2: single-pass compaction (each disparity is read once).
+// K2: single-pass compaction (each disparity is read once) -- the PROTOCOL and the PIPELINE every form below shares.
 //  * A block serves ONE frame at a time (frame = blockIdx % n_frames) and
 //    takes that frame's tiles from the frame's own ticket counter: every
 //    predecessor of a tile is already running (or done) when the tile starts,
@@ -31,12 +31,15 @@ namespace d2pc {
 //  * 5 waves per block: four WORKER waves stream pixels; one CONTROL wave
 //    owns the protocol (ticket atomics, publishing, polling), so the workers
 //    never sit behind an atomic's round trip.
-//  * Software pipeline over a block's tiles, holding only DISPARITIES in
-//    registers: iteration i COUNTS tile t (exact validity predicate, a few
-//    operations per pixel for a stereoRectify-structured Q), the control wave
-//    publishes t, fetches the ticket of t+1 and waits for the prefix of t-1
-//    (published an iteration ago, so normally ready at the first look); then
-//    t+1's loads are issued and tile t-1 is reprojected and scattered.
+//  * Software pipeline over a block's tiles; the tiles in flight live in a
+//    4-stage LDS ring, not in registers: iteration i COUNTS tile t (exact
+//    validity predicate, a few operations per pixel for a stereoRectify-
+//    structured Q), the control wave publishes t, fetches the ticket of t+1
+//    and waits for the prefix of t-2 (published two iterations ago, so
+//    normally ready at the first look); then t+1's loads are issued and
+//    tile t-2 is reprojected and scattered.
+// The product's kernel is K2d (k_compact_onepass_dense) below; "K2" alone names
+// round 4's form of the two phases (k_compact_onepass, experiment build).
 // --------------------------------------------------------------------------
 // ---- single-pass building blocks: validity and points of one wave's share of a tile -------------------
 
@@ -61,11 +64,11 @@ __device__ __forceinline__ uint64_t vgpr_pointer(const void *p) {
 }
 
 // --------------------------------------------------------------------------
-// K2d: the single pass with INPUT-SIDE compaction (round 5).  Same protocol, same pipeline, same bytes out as K2 above;
-// what differs is what waits in LDS between a tile's count and its scatter.  K2 keeps the tile's raw disparities and
-// decides every pixel a second time in the scatter phase: all 8 slots of a wave run the fp64 division and issue a
-// store instruction whose lanes are ragged -- with 30 % of the pixels invalid the launch executes the instructions and
-// the L1 -> L2 write requests of an all-valid one (profiles/r04_compact_counters.json), with 90 % invalid it still takes
+// K2d: the single pass with INPUT-SIDE compaction (round 5; the product's).  Same protocol, same pipeline, same bytes out
+// as round 4's K2; what differs is what waits in LDS between a tile's count and its scatter.  K2 kept the tile's raw disparities and
+// decided every pixel a second time in the scatter phase: all 8 slots of a wave ran the fp64 division and issued a
+// store instruction whose lanes were ragged -- with 30 % of the pixels invalid the launch executed the instructions and
+// the L1 -> L2 write requests of an all-valid one (profiles/r04_compact_counters.json), with 90 % invalid it still took
 // 340 us per 16 x 4K (the scatter phase alone 5,100 of 10,000 cycles per iteration: profiles/r05_onepass_phases.txt).
 // Here the COUNT phase -- which knows every pixel's validity anyway -- packs the survivors of each run of 256 consecutive
 // pixels to the front of the run's own LDS slice (4 bytes of disparity + 1 byte of offset inside the run: round 2
