@@ -715,14 +715,15 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     // phase runs dense (round 5: the product's); experiment build: 1 = raw tiles in LDS, every pixel decided in both phases
     // (rounds 2-4), 3 = form 2 with 8 worker waves on tiles of 4,096 pixels, 4 = form 2 with the control wave as the loader
     a.onepass_form = ctx->onepass_form ? ctx->onepass_form : kDefaultOnepassForm;
-    const int form_pxt = a.onepass_form == 3 ? 16 : a.onepass_form >= 2 ? 8 : int(g.pxt);
+    const bool big_tiles = a.onepass_form == 3 || a.onepass_form == 5 || a.onepass_form == 7;
+    const int form_pxt = big_tiles ? 16 : a.onepass_form >= 2 ? 8 : int(g.pxt);
     if (form_pxt != int(g.pxt)) {
       Geom gf = g;
       retile(&gf, form_pxt);
       a.geom = gf;
       a.pxt = form_pxt;
     }
-    const int dflt_per_cu = a.onepass_form == 3 ? 2 : (a.geom.tiles_per_frame >= 2048 ? 3 : 4);
+    const int dflt_per_cu = big_tiles ? 2 : (a.geom.tiles_per_frame >= 2048 ? 3 : 4);
     const int per_cu = ctx->onepass_blocks_per_cu ? ctx->onepass_blocks_per_cu : dflt_per_cu;
     const uint32_t persistent = uint32_t(ctx->cu_count) * uint32_t(per_cu);
     a.grid = a.geom.total_tiles < persistent ? a.geom.total_tiles : persistent;
@@ -758,7 +759,7 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
   a.state_bytes = compact_state_bytes(a.geom);
   a.stats = ctx->d_stats;
   // the dense single pass cleans up for its successor: two states per buffer (see StateBuf::pp_*)
-  const bool self_clean = a.compact_algo == 2 && a.onepass_form == 2;
+  const bool self_clean = a.compact_algo == 2 && a.onepass_form >= 2 && a.onepass_form != 4;  // (every dense form)
   const size_t half = (a.state_bytes + 255) & ~size_t(255);
   StateBuf *sb = nullptr;
   int st = acquire_buf(ctx, ctx->states, stream, self_clean ? 2 * half : a.state_bytes, 0, fixed_state, &sb);
@@ -1160,7 +1161,7 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value) {
   else if (!strcmp(key, "pxt_compact") && tile_shape_supported(value)) ctx->pxt_compact = value;
   else if (!strcmp(key, "blocks_per_cu") && value >= 1 && value <= 4096) ctx->blocks_per_cu = value;
   else if (!strcmp(key, "onepass_blocks_per_cu") && value >= 0 && value <= 64) ctx->onepass_blocks_per_cu = value;
-  else if (!strcmp(key, "onepass_form") && (value == 0 || value == 2 || (D2PC_EXPERIMENTS && value >= 1 && value <= 4))) ctx->onepass_form = value;
+  else if (!strcmp(key, "onepass_form") && (value == 0 || value == 2 || (D2PC_EXPERIMENTS && value >= 1 && value <= 7))) ctx->onepass_form = value;
   else if (!strcmp(key, "no_vec_rows") && (value == 0 || value == 1)) ctx->no_vec_rows = value;
   else if (!strcmp(key, "stage_timing") && (value == 0 || value == 1)) ctx->stage_timing = value;
   else if (!strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 40000) ctx->spin_timeout_ms = value;

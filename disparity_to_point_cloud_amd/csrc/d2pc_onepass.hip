@@ -101,14 +101,14 @@ struct SelfClean {
   CompactStats *stats;
 };
 
-template <int DT, int NW, bool VEC>
+template <int DT, int NW, bool VEC, int RPW = 2>
 struct RunFetch {
-  v4f q[VEC ? 2 : 1];
-  float d[VEC ? 1 : 8];
+  v4f q[VEC ? RPW : 1];
+  float d[VEC ? 1 : 4 * RPW];
   // requests the wave's two runs of tile `base` (all loads in flight; nothing is waited for here)
   __device__ __forceinline__ void issue(const uint8_t *fin, const Geom &g, uint32_t base, uint32_t wave, uint32_t lane) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < RPW; ++b) {
       const uint32_t run_base = base + (uint32_t(b) * uint32_t(NW) + wave) * 256u;
       if constexpr (VEC) {
         const uint32_t i = run_base + lane * 4u;
@@ -130,7 +130,7 @@ struct RunFetch {
   // lands them, pixel-linear, in the wave's two run slices of an LDS stage
   __device__ __forceinline__ void finish(float *stage, uint32_t wave, uint32_t lane) const {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < RPW; ++b) {
       float *run = stage + (uint32_t(b) * uint32_t(NW) + wave) * 256u;
       if constexpr (VEC) {
         *reinterpret_cast<v4f *>(run + lane * 4u) = q[b];
@@ -239,13 +239,15 @@ __device__ __forceinline__ void run_scatter_dense(const QArg<QK> &Q, const Geom 
   }
 }
 
-template <int DT, int QK, int NW, bool VEC>
+// RPW: runs of 256 pixels per worker wave and tile (2: tiles of 512 NW pixels).  DEFER: a tile's loads fly for a whole
+// iteration (its ticket is taken two tiles ahead of its count; one barrier per iteration).
+template <int DT, int QK, int NW, bool VEC, int RPW = 2, bool DEFER = false>
 __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const uint8_t *__restrict__ disp, float4 *__restrict__ out,
                                                                          uint32_t *__restrict__ out_index,
                                                                          uint32_t *__restrict__ counts, uint8_t *state, const Geom g,
                                                                          const QArg<QK> Q, const SelfClean sc) {
   using gu64 = __attribute__((address_space(1))) uint64_t;
-  constexpr int RUNS = 2 * NW;
+  constexpr int RUNS = RPW * NW;
   constexpr uint32_t TILE = uint32_t(RUNS) * 256u;
   static_assert(RUNS <= 64, "one wave scans a tile's run counts");
   __shared__ uint32_t s_cnt2[2][RUNS];  // (two buffers: with ONE barrier per iteration the control wave scans tile t's counts while the workers count t + 1)
@@ -290,17 +292,30 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
   float4 *fout = out + uint64_t(f) * g.out_frame_stride;
   uint32_t *fidx = out_index ? out_index + uint64_t(f) * g.out_frame_stride : nullptr;
 
-  if (ctl && lane == 0) s_next[1] = atomicAdd(fs.ticket, 1u);
+  if (ctl && lane == 0) {
+    s_next[1] = atomicAdd(fs.ticket, 1u);
+    if constexpr (DEFER) s_next[0] = atomicAdd(fs.ticket, 1u);
+  }
   __syncthreads();
   uint32_t cur = s_next[1];
   if (cur >= g.tiles_per_frame) cur = kNoTile;
   uint32_t prev = kNoTile, prev2 = kNoTile;  // counted one / two iterations ago; prev2 is scattered now
   KnownGroups known;
-  RunFetch<DT, NW, VEC> fetch;
+  RunFetch<DT, NW, VEC, RPW> fetch;
   const uint64_t vout = vgpr_pointer(fout), vidx = vgpr_pointer(fidx);
   if (!ctl && cur != kNoTile) {
     fetch.issue(fin, g, cur * TILE, wave, lane);
     fetch.finish(s_tile, wave, lane);  // iteration 0 counts stage 0
+  }
+  // `nx` is counted in the NEXT iteration: its loads were issued one iteration ago and land behind this iteration's
+  // barrier, so they have had a whole count phase + barrier to arrive and the wait for them is static (vmcnt(0) with
+  // nothing younger outstanding but stores that are a scatter old)
+  uint32_t nx = kNoTile;
+  if constexpr (DEFER) {
+    if (cur != kNoTile) nx = s_next[0];
+    if (nx >= g.tiles_per_frame) nx = kNoTile;
+    __syncthreads();  // (s_next[0] is written again in iteration 0)
+    if (!ctl && nx != kNoTile) fetch.issue(fin, g, nx * TILE, wave, lane);
   }
 
   for (uint32_t it = 0; cur != kNoTile || prev != kNoTile || prev2 != kNoTile; ++it) {
@@ -309,12 +324,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
     D2PC_STAMP(c0);
     if (ctl) {
       uint32_t tk = 0;
-      if (cur != kNoTile && lane == 0) tk = atomicAdd(fs.ticket, 1u);  // (its round trip runs under the polls)
+      const bool more = (DEFER ? nx : cur) != kNoTile;
+      if (more && lane == 0) tk = atomicAdd(fs.ticket, 1u);  // (its round trip runs under the polls)
       if (prev2 != kNoTile) {
         const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, polls, known, g.spin_ticks);
         if (lane == 0) s_prefix[slot] = p;
       }
-      if (cur != kNoTile && lane == 0) s_next[slot] = tk;
+      if (more && lane == 0) s_next[slot] = tk;
 #if D2PC_ONEPASS_STATS
       if (cur != kNoTile && lane == 0) s_stat[0] += 1u;
 #endif
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
       float *stage = s_tile + (it & 3u) * uint32_t(RUNS * 256);
       uint8_t *offs = s_off + ring * uint32_t(RUNS * 256);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < RPW; ++b) {
         const uint32_t r = uint32_t(b) * uint32_t(NW) + wave;
         const uint32_t c = run_count_pack<QK>(Q, g, stage + r * 256u, offs + r * 256u, cur * TILE + r * 256u, lane);
         if (lane == 0) s_cnt2[slot][r] = c;
@@ -332,11 +348,18 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
     __syncthreads();
     D2PC_STAMP(c2);
     uint32_t next = kNoTile;
-    if (cur != kNoTile) {
+    if ((DEFER ? nx : cur) != kNoTile) {
       next = s_next[slot];
       if (next >= g.tiles_per_frame) next = kNoTile;
     }
-    if (!ctl && next != kNoTile) fetch.issue(fin, g, next * TILE, wave, lane);  // fly while the control wave scans and publishes
+    if constexpr (DEFER) {
+      if (!ctl) {
+        if (nx != kNoTile) fetch.finish(s_tile + ((it + 1u) & 3u) * uint32_t(RUNS * 256), wave, lane);  // issued an iteration ago
+        if (next != kNoTile) fetch.issue(fin, g, next * TILE, wave, lane);                              // lands an iteration from now
+      }
+    } else {
+      if (!ctl && next != kNoTile) fetch.issue(fin, g, next * TILE, wave, lane);  // fly while the control wave scans and publishes
+    }
     if (ctl && cur != kNoTile) {
       const uint32_t c = lane < uint32_t(RUNS) ? s_cnt2[slot][lane] : 0u;
       uint32_t total;
@@ -353,12 +376,12 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
       }
     }
 #if !D2PC_DENSE_ONE_BARRIER
-    __syncthreads();
+    if constexpr (!DEFER) __syncthreads();
 #endif
     D2PC_STAMP(c3);
     if (!ctl) {
 #if !D2PC_DENSE_LAND_LATE
-      if (next != kNoTile) fetch.finish(s_tile + ((it + 1u) & 3u) * uint32_t(RUNS * 256), wave, lane);
+      if (!DEFER && next != kNoTile) fetch.finish(s_tile + ((it + 1u) & 3u) * uint32_t(RUNS * 256), wave, lane);
 #endif
 #ifdef D2PC_DIAG
       {
@@ -371,7 +394,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
         const uint8_t *offs = s_off + ring2 * uint32_t(RUNS * 256);
         const uint32_t prefix = s_prefix[slot];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < RPW; ++b) {
           const uint32_t r = uint32_t(b) * uint32_t(NW) + wave;
           const uint32_t c = __builtin_amdgcn_readfirstlane(s_rcnt[ring2][r]);
           const uint32_t pos0 = prefix + __builtin_amdgcn_readfirstlane(s_excl[ring2][r]);
@@ -403,7 +426,12 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
 #endif
     prev2 = prev;
     prev = cur;
-    cur = next;
+    if constexpr (DEFER) {
+      cur = nx;
+      nx = next;
+    } else {
+      cur = next;
+    }
   }
   __syncthreads();
   if (counts && tid == 0 && __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -1009,16 +1037,16 @@ static hipError_t launch_onepass_tiles(const LaunchArgs &a, uint32_t grid) {
 
 #endif  // D2PC_EXPERIMENTS
 
-template <int NW>
+template <int NW, int RPW = 2, bool DEFER = false>
 static hipError_t launch_onepass_dense(const LaunchArgs &a, uint32_t grid) {
-  if (a.geom.pxt != uint32_t(2 * NW)) return hipErrorInvalidValue;  // the geometry of 512 NW pixels per tile
+  if (a.geom.pxt != uint32_t(RPW * NW)) return hipErrorInvalidValue;  // the geometry of 256 RPW NW pixels per tile
   return for_q_kind(a.q_kind, [&](auto qk) {
     return for_dtype_vec(a, [&](auto dt, auto vec) {
       constexpr int QK = decltype(qk)::value, DT = decltype(dt)::value;
       constexpr bool VEC = decltype(vec)::value;
       const SelfClean sc{static_cast<uint4 *>(a.state_other), uint32_t((a.state_bytes + 15) / 16), a.state_is_clean ? 1u : 0u,
                          static_cast<CompactStats *>(a.stats)};
-      hipLaunchKernelGGL((k_compact_onepass_dense<DT, QK, NW, VEC>), dim3(grid), dim3(64 * (NW + 1)), 0, a.stream,
+      hipLaunchKernelGGL((k_compact_onepass_dense<DT, QK, NW, VEC, RPW, DEFER>), dim3(grid), dim3(64 * (NW + 1)), 0, a.stream,
                          static_cast<const uint8_t *>(a.disp), static_cast<float4 *>(a.out_points), a.out_index, a.counts,
                          static_cast<uint8_t *>(a.state), a.geom, make_qarg<QK>(a), sc);
       return hipGetLastError();
@@ -1038,6 +1066,9 @@ hipError_t launch_onepass(const LaunchArgs &a) {
   if (a.onepass_form == 2) return launch_onepass_dense<4>(a, grid);
 #if D2PC_EXPERIMENTS
   if (a.onepass_form == 3) return launch_onepass_dense<8>(a, grid);
+  if (a.onepass_form == 5) return launch_onepass_dense<4, 4>(a, grid);        // 4 workers x 4 runs: tiles of 4,096 pixels
+  if (a.onepass_form == 6) return launch_onepass_dense<4, 2, true>(a, grid);  // deferred landing
+  if (a.onepass_form == 7) return launch_onepass_dense<4, 4, true>(a, grid);  // both
   if (a.onepass_form == 4) {
     if (a.geom.pxt != 8u) return hipErrorInvalidValue;
     return for_q_kind(a.q_kind, [&](auto qk) {

@@ -91,7 +91,7 @@ def test_chunked_two_pass_whatever_the_chunking(chunk_mb, first, dtype):
         assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"frame {f}")
 
 
-@pytest.mark.parametrize("form", [1, 2, 3, 4])
+@pytest.mark.parametrize("form", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("case", ["f32", "f32_unaligned", "u8", "u16", "general", "sliver", "narrow", "min_disparity", "cv24"])
 def test_single_pass_kernel_forms(form, case):
     """The single pass (compact_algo 2) in its kernel forms -- tuning "onepass_form": 2 = the product's (the count phase packs
@@ -146,7 +146,7 @@ def test_single_pass_kernel_forms(form, case):
         assert_points_close(pts, wp, max_ulp=ulp, rel=1e-5, what=f"frame {f}")
 
 
-@pytest.mark.parametrize("form", [2, 3, 4])
+@pytest.mark.parametrize("form", [2, 3, 4, 5, 6, 7])
 def test_single_pass_dense_forms_at_4k(form):
     q = d2pc.make_q()
     kinds = ["uniform", "holes", "blocky", "holes", "uniform"]
