@@ -714,6 +714,8 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
     // which single-pass kernel (tuning "onepass_form"; same bytes out): 2 = the count phase packs the survivors, the scatter
     // phase runs dense (round 5: the product's); experiment build: 1 = raw tiles in LDS, every pixel decided in both phases
     // (rounds 2-4), 3 = form 2 with 8 worker waves on tiles of 4,096 pixels, 4 = form 2 with the control wave as the loader
+    // 5 = form 2 with 4 runs per worker wave (4,096-pixel tiles), 6 = form 2 with deferred landing (a tile's loads fly for a
+    // whole iteration), 7 = 5 + 6: profiles/r05_ab_forms567.txt
     a.onepass_form = ctx->onepass_form ? ctx->onepass_form : kDefaultOnepassForm;
     const bool big_tiles = a.onepass_form == 3 || a.onepass_form == 5 || a.onepass_form == 7;
     const int form_pxt = big_tiles ? 16 : a.onepass_form >= 2 ? 8 : int(g.pxt);

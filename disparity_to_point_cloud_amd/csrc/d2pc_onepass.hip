@@ -286,7 +286,10 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
 #define D2PC_STAMP(x)
 #endif
 
-  const uint32_t f = blockIdx.x % g.n_frames;  // a block serves ONE frame (the launcher sizes the grid to a multiple of n_frames)
+  // a block serves ONE frame (the launcher sizes the grid to a multiple of n_frames).  Blocks are dealt to the 8 XCDs
+  // round-robin, so with a multiple of 8 frames all the blocks of a frame share an XCD and its L2: their hand-off words
+  // are then seen 0.2-0.6 us after the store instead of 0.7-1.0 us across XCDs (profiles/r05_xcd_handoff.txt)
+  const uint32_t f = blockIdx.x % g.n_frames;
   const FrameState fs(state, g, f);
   const uint8_t *fin = disp + uint64_t(f) * g.in_frame_stride;
   float4 *fout = out + uint64_t(f) * g.out_frame_stride;
