@@ -390,7 +390,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
   __shared__ uint32_t s_cnt[32], s_base[32];
   __shared__ uint32_t s_stat[3];
   const uint32_t tid0 = threadIdx.x;
-  const uint32_t tid = tid0, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t tid = tid0, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
   const uint32_t f = blockIdx.x % g.n_frames;
   const CbCompactState cs(state, g, f, ma.tiles_y);
