@@ -98,7 +98,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
     D2PC_BS_ADD(0, 1);
     D2PC_BS_ADD(5, e1 - e0);
     D2PC_BS_ADD(6, e1 - diag_t0);
-    if (tid == 0) atomicAdd(&g_bs_diag[blockIdx.x & 255u][14], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - diag_r0));
+    if (tid == 0) atomicAdd(&g_bs_diag[blockIdx.x & 255u][7], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - diag_r0));
   }
 #endif
 }
@@ -404,6 +404,10 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
   uint8_t *lut_cls = reinterpret_cast<uint8_t *>(s_raw + 3 * 256);  // [256]
   static_assert(S::RAW_WORDS >= 3 * 256 + 64, "the tables fit where the staged rows were");
 
+#ifdef D2PC_DIAG  // stage timers: tools/diag_callback.py
+  const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long dA = 0, dB = 0, dC = 0, dD = 0, dE = 0, dN = 0;
+#endif
   if (tid == 0) {
     s_next = atomicAdd(cs.ticket, 1u);
     s_exact = !is_stereo(QK) ? 1u : 0u;
@@ -441,6 +445,10 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
     // device (profiles/r05_ab_callback_nohoist.txt); 0 spilled VGPRs, 0 bytes of scratch (round 4's verdict, item 3a).
     const uint32_t tid = opaque(tid0), lane = tid & 63u;
     uint32_t tk = 0, nxt = kNoTile;
+#ifdef D2PC_DIAG
+    const unsigned long long f1 = __builtin_amdgcn_s_memtime();
+    unsigned long long f0 = f1, f2 = f1, f3 = f1;
+#endif
     if (cur != kNoTile) {
       // the ticket of the tile after `cur`: its round trip runs under the filter
       if (tid == 0) tk = atomicAdd(cs.ticket, 1u);
@@ -449,6 +457,10 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
       // (Requesting the NEXT tile's rows one tile ahead, so that they would complete before this iteration's store
       // burst, was built and is slower -- 722 -> 788 us: the 12 registers it keeps across the phases spill.)
       median_bs_tile<KS>(fsrc, ma, int(x0), int(y0), s_w, s_raw, tid);
+#ifdef D2PC_DIAG
+      f0 = __builtin_amdgcn_s_memtime();
+      ++dN;
+#endif
       if (tid == 0) s_next = tk;
       if constexpr (is_stereo(QK)) {  // per byte value: 1/W, Z and the validity class (see K1c)
         const float d = __fmul_rn(float(tid), g.scale);
@@ -463,6 +475,9 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         if (cls == 2u) s_exact = 1u;  // (benign race: every writer stores 1; never reset)
       }
       __syncthreads();
+#ifdef D2PC_DIAG
+      f2 = __builtin_amdgcn_s_memtime();
+#endif
       exact = s_exact != 0;
       nxt = s_next < tpf ? s_next : kNoTile;
       // ---- count: survivors per row of `cur` -------------------------------------------------------------
@@ -488,6 +503,11 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         if (lane == 0) s_cnt[r] = cnt;
       }
       __syncthreads();
+#ifdef D2PC_DIAG
+      f3 = __builtin_amdgcn_s_memtime();
+      dA += f2 - f0;
+      dB += f3 - f2;
+#endif
       // ---- publish `cur` (wave 0): sixteen tagged dwords + the band's accumulator; nothing to wait for ------
       if (wave == 0) {
         const uint32_t mine = lane < 32u ? s_cnt[lane] : 0u;
@@ -503,6 +523,9 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         }
       }
     }
+#ifdef D2PC_DIAG
+    unsigned long long f5 = __builtin_amdgcn_s_memtime();
+#endif
     if (prev != kNoTile) {
       // ---- place `prev` (wave 0): its band published a whole filter ago -----------------------------------
       const uint32_t ty = prev / ma.tiles_x, tx = prev - ty * ma.tiles_x;
@@ -572,6 +595,9 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         }
       }
       lds_barrier();
+#ifdef D2PC_DIAG
+      f5 = __builtin_amdgcn_s_memtime();
+#endif
       // ---- scatter `prev` from the kept bytes: the same decisions, the points, their ordered stores ----------
       const uint8_t *kb = reinterpret_cast<const uint8_t *>(s_keep);
 #pragma unroll 1
@@ -601,6 +627,9 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         }
       }
     }
+#ifdef D2PC_DIAG
+    const unsigned long long f6 = __builtin_amdgcn_s_memtime();
+#endif
     // (LDS-only barriers from here to the filter: a full one would hold every wave until its stores have drained)
     lds_barrier();  // the scatter has read s_keep and the tables; the count has read s_w
     if (cur != kNoTile) {
@@ -609,9 +638,27 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         reinterpret_cast<uint4 *>(s_keep)[i] = reinterpret_cast<const uint4 *>(s_w)[i];
     }
     lds_barrier();
+#ifdef D2PC_DIAG
+    dC += f5 - f3;
+    dD += f6 - f5;
+    dE += __builtin_amdgcn_s_memtime() - f6;
+#endif
     prev = cur;
     cur = nxt;
   }
+#ifdef D2PC_DIAG
+  {
+    const uint32_t tid = tid0;
+    D2PC_BS_ADD(0, dN);
+    D2PC_BS_ADD(5, dA);
+    D2PC_BS_ADD(8, dB);
+    D2PC_BS_ADD(9, dC);
+    D2PC_BS_ADD(10, dD);
+    D2PC_BS_ADD(11, dE);
+    D2PC_BS_ADD(6, __builtin_amdgcn_s_memtime() - diag_t0);
+    if (tid == 0) atomicAdd(&g_bs_diag[blockIdx.x & 255u][7], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - diag_r0));
+  }
+#endif
   if (tid == 0) {
     // a block that saw the launch break marks its frame, whether or not the frame's last tile has reported already
     if (counts && __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -744,12 +791,12 @@ hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const v
 
 #ifdef D2PC_DIAG
 // diagnostic build only (tools/diag_callback.py): read and reset the stage timers of the tile body
-extern "C" int d2pc_debug_read_bs_diag(unsigned long long *out16) {
-  static unsigned long long all[256][16];
+extern "C" int d2pc_debug_read_bs_diag(unsigned long long *out32) {
+  static unsigned long long all[256][32];
   if (hipMemcpyFromSymbol(all, HIP_SYMBOL(d2pc::g_bs_diag), sizeof all) != hipSuccess) return 6;
-  for (int i = 0; i < 16; ++i) {
-    out16[i] = 0;
-    for (int s = 0; s < 256; ++s) out16[i] += all[s][i];
+  for (int i = 0; i < 32; ++i) {
+    out32[i] = 0;
+    for (int s = 0; s < 256; ++s) out32[i] += all[s][i];
   }
   for (auto &row : all)
     for (auto &x : row) x = 0;

@@ -38,13 +38,15 @@ namespace d2pc {
 #ifdef D2PC_DIAG
 // diagnostic build: shader-clock sums per stage of the tile body, added by wave 0's lane 0 of every block
 // (tools/diag_callback.py): [0] tiles, [1] rows requested -> staged in LDS, [2] plane words, [3] select, [4] bytes back,
-// [5] the caller's epilogue, [6] block lifetime, [7] the same in 100 MHz ticks; [8..13] the same stamps for the block's LAST wave
-// (256 slots of 16 words, one 128-byte line each, picked by the block index: thousands of blocks adding to ONE word serialise at
-// the memory side and tripled the kernel's time in the first form of this diagnostic)
-inline __device__ unsigned long long g_bs_diag[256][16];
+// [5] the caller's epilogue (COMPACT body: table + barrier), [6] block lifetime, [7] the same in 100 MHz ticks, COMPACT body:
+// [8] count + barrier, [9] publish + place (wave 0; the last wave waits here), [10] scatter, [11] tile kept + barriers;
+// [16..31] the same stamps for the block's LAST wave
+// (256 slots of 32 words, two 128-byte lines each, picked by the block index: thousands of blocks adding to ONE word serialise
+// at the memory side and tripled the kernel's time in the first form of this diagnostic)
+inline __device__ unsigned long long g_bs_diag[256][32];
 #define D2PC_BS_STAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
 #define D2PC_BS_ADD(i, v) \
-  do { if ((tid & 63u) == 0u && ((tid >> 6) == 0u || (tid >> 6) == 3u)) atomicAdd(&g_bs_diag[blockIdx.x & 255u][(i) + ((tid >> 6) == 3u ? 7 : 0)], (unsigned long long)(v)); } while (0)
+  do { if ((tid & 63u) == 0u && ((tid >> 6) == 0u || (tid >> 6) == 3u)) atomicAdd(&g_bs_diag[blockIdx.x & 255u][(i) + ((tid >> 6) == 3u ? 16 : 0)], (unsigned long long)(v)); } while (0)
 #else
 #define D2PC_BS_STAMP(x)
 #define D2PC_BS_ADD(i, v)
