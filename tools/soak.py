@@ -58,7 +58,7 @@ for c in range(cases):
         if algo == 4:
             ctx.set_tuning("chunk_mb", int(rng.choice([1, 2, 96])))
         if algo == 2:   # the single pass in its kernel forms (0 = the product's default, form 2; 1 / 3 / 4: experiment build)
-            ctx.set_tuning("onepass_form", int(rng.choice([0, 0, 1, 2, 3, 4])))
+            ctx.set_tuning("onepass_form", int(rng.choice([0, 0, 1, 2, 3, 4, 5, 6, 7])))
         if algo == 3:   # the ordinary resident tile, or the register-resident blocks of 32 / 64 pixels per thread
             ctx.set_tuning("resident_pxt", int(rng.choice([0, 32, 64])))
             ctx.set_tuning("resident_stagger_pct", int(rng.choice([-1, 0, 100])))

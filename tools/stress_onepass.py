@@ -30,7 +30,7 @@ while done < launches:
     if rng.random() < 0.2: w, h = 3840, 2160; n = min(n, 16)
     border = int(rng.choice([0, 8, 40]))
     if w <= 2 * border or h <= 2 * border: continue
-    form = int(rng.choice([0, 0, 0, 2, 1, 3, 4]))   # the single pass's kernel form (0 / 2: the product's dense pass)
+    form = int(rng.choice([0, 0, 0, 2, 1, 3, 4, 5, 6, 7]))   # the single pass's kernel form (0 / 2: the product's dense pass)
     pxt = int(rng.choice([4, 8, 16])); opbpc = int(rng.choice([1, 2, 3, 4, 6, 8])); idx = bool(rng.integers(0, 2))
     holes = float(rng.choice([0.0, 0.02, 0.3, 0.7, 0.98]))
     disp = torch.rand((n, h, w), generator=g, device="cuda") * 127.5 + 0.5
