@@ -103,7 +103,9 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * CU, default 8; 0 = one block per "membench_unroll" x 4 KiB), "membench_unroll" (1, 2 or 4 16-byte accesses per thread),
  * "membench_nt" (0/1), "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process /
  * d2pc_process_mono8 without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose
- * per launch, 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes).
+ * per launch, 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes),
+ * "onepass_form" (0 = choose, 2 = the dense single pass: the only form of the product), "resident_pair" (two 4K-class
+ * COMPACT frames in one call: 0 = one launch each (default), 1 = round 4's one launch of blocks twice the size).
  *
  * EXPERIMENT BUILD (libd2pc_exp.so = the same sources with -DD2PC_EXPERIMENTS=1, `make -C csrc exp`; what tests/ and
  * tools/ load to re-run recorded negatives; never shipped, never what INTEGRATION.md links).  It adds, and only it
@@ -111,7 +113,9 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * than the single pass: docs/HISTORY.md) with its keys "big_batch_algo" (2 / 4: what compact_algo 0 takes for big
  * batches) and the two that size its pieces; "resident_unbounded" (0/1: the resident form over more blocks than are
  * resident); "pxt_parity" 4 / 8 / 16 (the tile-walking PARITY kernel of rounds 1-2) and "parity_small"; "pxt_compact" 4 / 16;
- * test hook "general_q_form" = 1 (round 2's fused evaluation of a general Q). */
+ * "onepass_form" 1 (rounds 2-4's single pass) and 3-7 (round 5's other forms: 8 worker waves, loader wave, 4 runs per
+ * wave, deferred landing, both -- profiles/r05_ab_onepass_forms_*.txt, r05_ab_forms567.txt); "median_algo" 3 (the select
+ * split over a lane pair); test hook "general_q_form" = 1 (round 2's fused evaluation of a general Q). */
 int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 
 
