@@ -36,6 +36,16 @@ __device__ __forceinline__ unsigned long long get(unsigned long long *p) {
   if (L == 4) v = __hip_atomic_load((g64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (L == 5) v = __hip_atomic_fetch_add((g64 *)p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (L == 6) asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  if (L == 7) {  // the SCALAR path (scalar data cache -> L2), bypassing the scalar cache
+    unsigned long long sv;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv) : "s"(p) : "memory");
+    v = sv;
+  }
+  if (L == 8) {  // scalar path, scalar cache invalidated first, no glc
+    unsigned long long sv;
+    asm volatile("s_dcache_inv\n\ts_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv) : "s"(p) : "memory");
+    v = sv;
+  }
   return v;
 }
 template <int S, int L>
@@ -92,7 +102,9 @@ void run(Shared *d, int consumer_xcc, const char *sname, const char *lname) {
   run<S, 3>(d, cx, SN, "buffer_inv sc1 + plain load");            \
   run<S, 4>(d, cx, SN, "load sc1 (agent scope)");                 \
   run<S, 5>(d, cx, SN, "atomic add 0, returning (no sc1)");       \
-  run<S, 6>(d, cx, SN, "load nt");
+  run<S, 6>(d, cx, SN, "load nt");                                \
+  run<S, 7>(d, cx, SN, "s_load glc (scalar path)");               \
+  run<S, 8>(d, cx, SN, "s_dcache_inv + s_load");
 int main() {
   Shared *d;
   hipMalloc(&d, sizeof(Shared));
