@@ -280,6 +280,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
   }
 #ifdef D2PC_DIAG  // phase timers (shader clock), as in k_compact_onepass: tools/diag_onepass.py
   unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, nIt = 0;
+  [[maybe_unused]] unsigned long long tS0 = 0, tS1 = 0, tS2 = 0;
   const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
 #define D2PC_STAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
 #else
@@ -328,12 +329,32 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
     if (ctl) {
       uint32_t tk = 0;
       const bool more = (DEFER ? nx : cur) != kNoTile;
-      if (more && lane == 0) tk = atomicAdd(fs.ticket, 1u);  // (its round trip runs under the polls)
+#if defined(D2PC_DIAG) && defined(D2PC_DIAG_CTL_SPLIT)
+      // the control wave's three round trips one after the other (NOT the product's order): what is left of the publishing
+      // stores' acknowledgement, the prefix poll alone, the ticket atomic alone (profiles/r05_ctl_split.txt)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+      if (prev2 != kNoTile) {
+        const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, polls, known, g.spin_ticks);
+        if (lane == 0) s_prefix[slot] = p;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+      if (more && lane == 0) tk = atomicAdd(fs.ticket, 1u);
+      if (more && lane == 0) s_next[slot] = tk;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+      tS0 += s0 - c0, tS1 += s1 - s0, tS2 += s2 - s1;
+#else
+      // (the compiler's wave-aggregated atomicAdd reads its result back where it is issued -- s_waitcnt vmcnt(0) --, so the
+      //  ticket's round trip, ~1,600 cycles, does NOT run under the polls: profiles/r05_ctl_split.txt)
+      if (more && lane == 0) tk = atomicAdd(fs.ticket, 1u);
       if (prev2 != kNoTile) {
         const uint32_t p = prefix_before<true>(fs, hdr, prev2, lane, polls, known, g.spin_ticks);
         if (lane == 0) s_prefix[slot] = p;
       }
       if (more && lane == 0) s_next[slot] = tk;
+#endif
 #if D2PC_ONEPASS_STATS
       if (cur != kNoTile && lane == 0) s_stat[0] += 1u;
 #endif
@@ -464,9 +485,15 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
   if (lane == 0 && ctl) {
     atomicAdd(&hdr->diag[1], (unsigned long long)s_stat[1]);
     atomicAdd(&hdr->diag[6], tA);
+#ifdef D2PC_DIAG_CTL_SPLIT  // (in place of the control wave's other three phases: tools/diag_onepass.py prints them under those names)
+    atomicAdd(&hdr->pad2[4], tS0);
+    atomicAdd(&hdr->pad2[5], tS1);
+    atomicAdd(&hdr->pad2[6], tS2);
+#else
     atomicAdd(&hdr->pad2[4], tB);
     atomicAdd(&hdr->pad2[5], tC);
     atomicAdd(&hdr->pad2[6], tD);
+#endif
   }
 #endif
 #undef D2PC_STAMP
