@@ -793,7 +793,9 @@ int enqueue(d2pc_ctx *ctx, const Geom &g, const void *d_disp, int dtype, void *d
 #endif
   sb->algo = a.compact_algo;
   sb->epoch = a.epoch;
-  D2PC_HIP(ctx, launch_compact(a));
+  const hipError_t launched = launch_compact(a);
+  if (launched != hipSuccess) sb->pp_clean = false;  // (nothing ran: the half this launch was to zero for its successor is still dirty)
+  D2PC_HIP(ctx, launched);
   if (!sb->captured) sb->dirty = true;  // (a captured buffer is never shared; for the others `done` is recorded when somebody asks)
   return D2PC_OK;
 }
