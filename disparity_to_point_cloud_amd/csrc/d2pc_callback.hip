@@ -374,6 +374,63 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
 // its current tile, so if every block of a frame waited, every issued tile would be published and each block's
 // previous tile would lie in the one band that still has unissued tiles -- more blocks than that band has tiles.
 // --------------------------------------------------------------------------
+// The first look at the words that place a tile (wave 0 of k_callback_bs_compact_pipe): the band accumulators above the
+// tile's band (up to 128 bands: two per lane) and the row counts of the band's tiles (lane = 16 j + p reads dword p of
+// tiles j, j + 4, ...: up to 4 per lane = 16 tiles across), requested in one place and examined in another.
+struct CbEarlyPlace {
+  using gu32 = __attribute__((address_space(1))) uint32_t;
+  using gu64 = __attribute__((address_space(1))) uint64_t;
+  static constexpr int kBands = 2, kTiles = 4;  // (images up to 4,096 x 4,096 output pixels; larger ones poll as before)
+  uint64_t band[kBands];
+  uint32_t row[kTiles];
+  bool fits = false;
+  __device__ __forceinline__ void request(const CbCompactState &cs, const MedianArgs &ma, uint32_t tile, uint32_t lane) {
+    const uint32_t ty = tile / ma.tiles_x;
+    fits = ty <= 64u * kBands && ma.tiles_x <= 4u * kTiles;
+    if (!fits) return;
+    const uint32_t j = lane >> 4, p = lane & 15u;
+#pragma unroll
+    for (int b = 0; b < kBands; ++b) {
+      const uint32_t bi = 64u * uint32_t(b) + lane;
+      band[b] = bi < ty ? __hip_atomic_load((gu64 *)(cs.band_acc + bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < kTiles; ++i) {
+      const uint32_t k = j + 4u * uint32_t(i);
+      row[i] = k < ma.tiles_x ? __hip_atomic_load((gu32 *)(cs.row_cnt + (ty * ma.tiles_x + k) * 16u + p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+  }
+  // the same sums the polling loop forms; false when any word was not final yet (or nothing was requested)
+  __device__ __forceinline__ bool take(const MedianArgs &ma, uint32_t ty, uint32_t tx, uint32_t lane, uint32_t &above, uint32_t &t0,
+                                       uint32_t &t1, uint32_t &l0, uint32_t &l1) const {
+    if (!fits) return false;
+    const uint32_t j = lane >> 4;
+    bool ok = true;
+    above = 0;
+#pragma unroll
+    for (int b = 0; b < kBands; ++b) {
+      const uint32_t bi = 64u * uint32_t(b) + lane;
+      if (bi < ty) {
+        ok = ok && uint32_t(band[b] >> 32) == ma.tiles_x;
+        above += uint32_t(band[b]);
+      }
+    }
+    t0 = t1 = l0 = l1 = 0;
+#pragma unroll
+    for (int i = 0; i < kTiles; ++i) {
+      const uint32_t k = j + 4u * uint32_t(i);
+      if (k < ma.tiles_x) {
+        const uint32_t v = row[i];
+        ok = ok && (v & kCbRowTag) != 0u;
+        const uint32_t c0 = v & 0x1ffu, c1 = (v >> 9) & 0x1ffu;
+        t0 += c0, t1 += c1;
+        if (k < tx) l0 += c0, l1 += c1;
+      }
+    }
+    return ok;
+  }
+};
+
 template <int KS, int QK>
 __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_callback_bs_compact_pipe(
     const uint8_t *__restrict__ src, float4 *__restrict__ out, uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
@@ -445,6 +502,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
     // device (profiles/r05_ab_callback_nohoist.txt); 0 spilled VGPRs, 0 bytes of scratch (round 4's verdict, item 3a).
     const uint32_t tid = opaque(tid0), lane = tid & 63u;
     uint32_t tk = 0, nxt = kNoTile;
+    CbEarlyPlace early{};  // (born in the iteration: nothing of it is alive across the filter)
 #ifdef D2PC_DIAG
     const unsigned long long f1 = __builtin_amdgcn_s_memtime();
     unsigned long long f0 = f1, f2 = f1, f3 = f1;
@@ -462,6 +520,9 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
       ++dN;
 #endif
       if (tid == 0) s_next = tk;
+      // the words that place `prev` are requested HERE by wave 0 and looked at behind the count: their round trip runs
+      // under the table, the count and two (LDS-only) barriers instead of in front of the scatter with three waves waiting
+      if (wave == 0 && prev != kNoTile) early.request(cs, ma, prev, lane);
       if constexpr (is_stereo(QK)) {  // per byte value: 1/W, Z and the validity class (see K1c)
         const float d = __fmul_rn(float(tid), g.scale);
         const float dsel = fabsf(d) < __builtin_huge_valf() ? d : __builtin_nanf("");
@@ -474,7 +535,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         lut_cls[tid] = uint8_t(cls);
         if (cls == 2u) s_exact = 1u;  // (benign race: every writer stores 1; never reset)
       }
-      __syncthreads();
+      lds_barrier();
 #ifdef D2PC_DIAG
       f2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -482,34 +543,66 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
       nxt = s_next < tpf ? s_next : kNoTile;
       // ---- count: survivors per row of `cur` -------------------------------------------------------------
       const uint8_t *ob = reinterpret_cast<const uint8_t *>(s_w);
-#pragma unroll 1
-      for (uint32_t r = wave; r < uint32_t(S::TH); r += uint32_t(S::THREADS / 64)) {
-        const uint32_t y = y0 + r;
-        uint32_t cnt = 0;
-        if (y < y_end) {
-          double ys = 0.0;
-          if constexpr (is_stereo(QK)) ys = stereo_ny(Q, y);
+      if (is_stereo(QK) && !exact) {
+        // a count needs no order: a lane takes 4 consecutive bytes of each of its wave's 8 rows (one word each, all eight
+        // requested before the first is used) and the class of each byte from the table.  Row by row, column by column
+        // (LDS byte -> table byte -> ballot, 32 dependent round trips per wave) this phase took 8,400 cycles per tile, now
+        // 3,600 (profiles/r05_callback_phases.txt)
+        constexpr int RPW = S::TH / (S::THREADS / 64);
+        uint32_t wrd[RPW];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t x = x0 + 64u * uint32_t(q) + lane;
-            const uint32_t raw = ob[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
-            double xs = 0.0;
-            if constexpr (is_stereo(QK)) xs = stereo_nx(Q, x);
-            float X, Y, Z;
-            const bool ok = pixel(x, y, raw, xs, ys, false, X, Y, Z) && x < x_end;
-            cnt += uint32_t(__popcll(__ballot(ok)));
-          }
+        for (int i = 0; i < RPW; ++i)
+          wrd[i] = reinterpret_cast<const uint32_t *>(ob + (wave + uint32_t(i) * uint32_t(S::THREADS / 64)) * uint32_t(S::OUT_STRIDE))[lane];
+        const uint32_t xl = x0 + 4u * lane;
+        // (the fences are scheduling boundaries: left to itself the compiler, short of registers for the select, issues
+        //  one table read, waits for it, uses it, and so on -- 40 dependent LDS round trips per wave)
+        asm volatile("" ::: "memory");
+        uint32_t cl[RPW][4];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) cl[i][b] = lut_cls[(wrd[i] >> (8 * b)) & 0xffu];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const uint32_t r = wave + uint32_t(i) * uint32_t(S::THREADS / 64);
+          uint32_t cnt = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) cnt += uint32_t(__popcll(__ballot(cl[i][b] == 1u && xl + uint32_t(b) < x_end)));
+          if (lane == 0) s_cnt[r] = y0 + r < y_end ? cnt : 0u;
         }
-        if (lane == 0) s_cnt[r] = cnt;
+      } else {
+#pragma unroll 1
+        for (uint32_t r = wave; r < uint32_t(S::TH); r += uint32_t(S::THREADS / 64)) {
+          const uint32_t y = y0 + r;
+          uint32_t cnt = 0;
+          if (y < y_end) {
+            double ys = 0.0;
+            if constexpr (is_stereo(QK)) ys = stereo_ny(Q, y);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t x = x0 + 64u * uint32_t(q) + lane;
+              const uint32_t raw = ob[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
+              double xs = 0.0;
+              if constexpr (is_stereo(QK)) xs = stereo_nx(Q, x);
+              float X, Y, Z;
+              const bool ok = pixel(x, y, raw, xs, ys, false, X, Y, Z) && x < x_end;
+              cnt += uint32_t(__popcll(__ballot(ok)));
+            }
+          }
+          if (lane == 0) s_cnt[r] = cnt;
+        }
       }
-      __syncthreads();
+      lds_barrier();
 #ifdef D2PC_DIAG
       f3 = __builtin_amdgcn_s_memtime();
       dA += f2 - f0;
       dB += f3 - f2;
 #endif
-      // ---- publish `cur` (wave 0): sixteen tagged dwords + the band's accumulator; nothing to wait for ------
-      if (wave == 0) {
+      // ---- publish `cur` (wave 1): sixteen tagged dwords + the band's accumulator; nothing to wait for.  Not wave 0: it
+      // places `prev` at the same time, and a wave's vector memory operations retire in order -- the words it requested
+      // for that would wait for these stores' acknowledgement ------
+      if (wave == 1u) {
         const uint32_t mine = lane < 32u ? s_cnt[lane] : 0u;
         const uint32_t tile_total = wave_sum(mine);
         if (lane < 16u)
@@ -534,9 +627,16 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         const uint32_t j = lane >> 4, p = lane & 15u;
         uint32_t above = 0, t0 = 0, t1 = 0, l0 = 0, l1 = 0, spins = 0;
         uint64_t w0 = 0;
+        bool first = cur != kNoTile;  // (the last tile of a block has no filter in front of its placing: nothing was requested)
         for (;;) {
           bool ok = true;
           above = 0;
+          if (first) {
+            first = false;
+            ok = early.take(ma, ty, tx, lane, above, t0, t1, l0, l1);
+            if (__all(ok)) break;
+            goto look_again;
+          }
           for (uint32_t b0 = 0; b0 < ty; b0 += 64u) {
             const uint32_t bi = b0 + lane;
             if (bi < ty) {
@@ -554,6 +654,7 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
             if (k < tx) l0 += c0, l1 += c1;
           }
           if (__all(ok)) break;
+        look_again:
           if (spins == 0) w0 = __builtin_amdgcn_s_memrealtime();
           backoff(spins);
           ++spins;
@@ -616,6 +717,8 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
           double xs = 0.0;
           if constexpr (is_stereo(QK)) xs = stereo_nx(Q, x);
           float X, Y, Z;
+          // (the row's table reads forced into flight together, as in the count phase, change nothing here: this phase is
+          //  bound by the CU's store path, ~210 cycles per wave-level store instruction -- profiles/r05_callback_phases.txt)
           const bool ok = pixel(x, y, raw[q], xs, ys, true, X, Y, Z) && x < x_end;
           const uint64_t m = __ballot(ok);
           const uint32_t pos = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), row_pos));

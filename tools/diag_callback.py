@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 import disparity_to_point_cloud_amd as d2pc
 from disparity_to_point_cloud_amd.torch_api import DeviceBatch
 
-lib = d2pc.load_library("diag")
+VARIANT = sys.argv[1] if len(sys.argv) > 1 else "diag"
+lib = d2pc.load_library(VARIANT)
 lib.d2pc_debug_read_bs_diag.argtypes = [ctypes.c_void_p]
 W, H, F = 3840, 2160, 16
 gen = torch.Generator(device="cuda").manual_seed(3)
@@ -26,7 +27,7 @@ FILTER = ["rows requested -> staged in LDS", "plane words", "the select", "plane
 
 
 def measure(mode, src, idx):
-    ctx = d2pc.Context(q=d2pc.make_q(), mode=mode, variant="diag")
+    ctx = d2pc.Context(q=d2pc.make_q(), mode=mode, variant=VARIANT)
     b = DeviceBatch(ctx, F, H, W, dtype=torch.uint8, want_index=idx)
     run = lambda: ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, W, H, W, W * H, F, 11, 0.125, b.points.data_ptr(),
                                           b.index.data_ptr() if idx else None, b.stride, b.counts.data_ptr(), s)
