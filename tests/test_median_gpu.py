@@ -755,6 +755,39 @@ def test_tile_fused_compact_kernel_with_more_frames_than_resident_bands(n, h, w)
         assert np.array_equal(res[2][1].view(np.uint32).reshape(n, -1)[f][:len(wi)], wi)
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 150, 4500), (2, 4300, 400), (3, 200, 4176)])
+def test_tile_fused_compact_kernel_beyond_the_early_look_of_its_placing_words(n, h, w):
+    """The pipelined kernel requests the words that place a tile early, into registers sized for images up to 16 tiles across
+    (4,096 output columns) and 128 bands (4,096 output rows); beyond either it polls as before.  4500 wide = 18 tiles
+    across, 4300 high = 132 bands, 4176 wide = exactly 16 tiles: all three against the two launches, bitwise, and the oracle."""
+    from disparity_to_point_cloud_amd.torch_api import DeviceBatch
+    rng = np.random.default_rng(h + w)
+    imgs = rng.integers(0, 256, size=(n, h, w)).astype(np.uint8)
+    imgs[rng.random((n, h, w)) < 0.3] = 0
+    src = torch.from_numpy(imgs).cuda()
+    res = {}
+    with d2pc.Context(q=d2pc.make_q(), mode=d2pc.MODE_COMPACT) as ctx:
+        ctx.set_tuning("median_algo", 2)
+        ctx.set_tuning("spin_timeout_ms", 500)
+        b = DeviceBatch(ctx, n, h, w, dtype=torch.uint8, want_index=True)
+        for fused in (2, 0):
+            ctx.set_tuning("callback_fused_compact", fused)
+            b.points.fill_(0)
+            b.index.fill_(-1)
+            b.counts.fill_(-7)
+            ctx.process_mono_device(src.data_ptr(), d2pc.DTYPE_U8, w, h, w, w * h, n, 11, 0.125, b.points.data_ptr(),
+                                    b.index.data_ptr(), b.stride, b.counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ctx.check_async_error()
+            res[fused] = (b.points.cpu().numpy().view(np.uint32).copy(), b.index.cpu().numpy().copy(), b.counts.cpu().numpy().copy())
+        assert ctx.compact_stats()["timeouts"] == 0
+    for a, c in zip(res[2], res[0]):
+        assert np.array_equal(a, c), "the pipelined kernel differs from the two launches"
+    want, wi = oracle.reproject_compact(oracle.median_u8(imgs[n - 1], 11), d2pc.make_q(), border=40, scale=0.125)
+    assert res[2][2].view(np.uint32)[n - 1] == len(want)
+    assert np.array_equal(res[2][1].view(np.uint32).reshape(n, -1)[n - 1][:len(wi)], wi)
+
+
 @pytest.mark.parametrize("form", [1, 2])
 def test_tile_fused_compact_kernel_is_capturable_and_runs_on_two_streams(form):
     """Captured without a warm-up call after d2pc_reserve_mono (its hand-off state is the capture's own), replayed
