@@ -701,6 +701,13 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
 #endif
       // ---- scatter `prev` from the kept bytes: the same decisions, the points, their ordered stores ----------
       const uint8_t *kb = reinterpret_cast<const uint8_t *>(s_keep);
+      // a lane's four columns do not change from row to row: (u + cx) is formed once per tile (two fp64-rate instructions
+      // fewer per pixel)
+      [[maybe_unused]] double xs4[4] = {0.0, 0.0, 0.0, 0.0};
+      if constexpr (is_stereo(QK)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xs4[q] = stereo_nx(Q, x0 + 64u * uint32_t(q) + lane);
+      }
 #pragma unroll 1
       for (uint32_t r = wave; r < uint32_t(S::TH); r += uint32_t(S::THREADS / 64)) {
         const uint32_t y = y0 + r;
@@ -711,14 +718,41 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
         uint32_t raw[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) raw[q] = kb[r * uint32_t(S::OUT_STRIDE) + 64u * uint32_t(q) + lane];
+        // the usual case (a calibrated Q, no sliver): the row's twelve table reads in flight together behind scheduling fences
+        // (see the count phase), the products only where a point is stored: -1 % of the launch (r05_ab_callback_stages.txt)
+        if constexpr (is_stereo(QK)) if (!exact) {
+          double t_iw[4];
+          float t_z[4];
+          uint32_t t_cls[4];
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            t_iw[q] = lut_iw[raw[q]];
+            t_z[q] = lut_z[raw[q]];
+            t_cls[q] = lut_cls[raw[q]];
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t x = x0 + 64u * uint32_t(q) + lane;
+            const float X = float(xs4[q] * t_iw[q]), Y = float(ys * t_iw[q]), Z = t_z[q];
+            const bool ok = t_cls[q] == 1u && x < x_end;
+            const uint64_t m = __ballot(ok);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), row_pos));
+            if (ok && pos < g.roi_n) {
+              store_point<D2PC_CB_STORE_NT != 0>(fout, pos, X, Y, Z);
+              if (fidx) st<D2PC_CB_INDEX_NT != 0>(fidx + pos, y * g.width + x);
+            }
+            row_pos += uint32_t(__popcll(m));
+          }
+          continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t x = x0 + 64u * uint32_t(q) + lane;
           double xs = 0.0;
           if constexpr (is_stereo(QK)) xs = stereo_nx(Q, x);
           float X, Y, Z;
-          // (the row's table reads forced into flight together, as in the count phase, change nothing here: this phase is
-          //  bound by the CU's store path, ~210 cycles per wave-level store instruction -- profiles/r05_callback_phases.txt)
           const bool ok = pixel(x, y, raw[q], xs, ys, true, X, Y, Z) && x < x_end;
           const uint64_t m = __ballot(ok);
           const uint32_t pos = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), row_pos));

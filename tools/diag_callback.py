@@ -64,3 +64,6 @@ v, us = measure(d2pc.MODE_COMPACT, blocky, True)
 print(f"# k_callback_bs_compact_pipe<11, stereo>, 30 % zero pixels in 64 x 64 blocks, + indices; kernel {us:.1f} us per launch under the "
       f"stamps; block clock {v[6] / max(v[7], 1) * 0.1:.2f} GHz (persistent blocks: cycles per TILE of the block)")
 table(v, FILTER + ["table + barrier", "count + barrier", "publish + place (+ barrier)", "scatter", "tile kept + barriers"], [1, 2, 3, 4, 5, 8, 9, 10, 11])
+v, us = measure(d2pc.MODE_COMPACT, blocky, False)
+print(f"# the same without indices; kernel {us:.1f} us per launch under the stamps; block clock {v[6] / max(v[7], 1) * 0.1:.2f} GHz")
+table(v, FILTER + ["table + barrier", "count + barrier", "publish + place (+ barrier)", "scatter", "tile kept + barriers"], [1, 2, 3, 4, 5, 8, 9, 10, 11])
