@@ -132,6 +132,28 @@ def fill_batch(batch, rank, kind):
     torch.cuda.synchronize()
 
 
+class RingLaunch:
+    """Camera-shaped launches: each launch() processes the next `n` frames of `batch`'s ring (inputs, outputs, index and count
+    slots all move on), so a launch never finds its frame in the Infinity Cache; fixed=True stays on the first position."""
+
+    def __init__(self, ctx, batch, n, fixed=False):
+        assert batch.n_frames % n == 0
+        self.ctx, self.b, self.n, self.fixed, self.pos = ctx, batch, n, fixed, 0
+        self.positions = batch.n_frames // n
+        self.stream = torch.cuda.current_stream(batch.device).cuda_stream
+
+    def launch(self):
+        b, f = self.b, self.pos * self.n
+        d = b.disp
+        fb = d.stride(0) * d.element_size()
+        self.ctx.process_device(d.data_ptr() + f * fb, d2pc.DTYPE_F32, 1.0, b.width, b.height, d.stride(1) * d.element_size(), fb,
+                                self.n, b.points.data_ptr() + f * b.stride * 16,
+                                (b.index.data_ptr() + f * b.stride * 4) if b.index is not None else None, b.stride,
+                                b.counts.data_ptr() + f * 4, self.stream)
+        if not self.fixed:
+            self.pos = (self.pos + 1) % self.positions
+
+
 def algorithmic_bytes(batch, n_points, with_index):
     """bytes = 4*R_in + 16*P (+4*P with indices), per launch."""
     r_in = batch.n_frames * batch.roi_n
@@ -278,19 +300,57 @@ def compaction_counters(ctx):
             "twopass_fallbacks": st["twopass_fallbacks"]}
 
 
-def valu_issue(key):
-    """The callback-body kernels are bound by VALU issue, not by HBM: next to their HBM fraction the line carries the
-    fraction of the chip's vector-issue slots they fill = VALU wave-instructions x 2 cycles (a wave64 instruction occupies
-    its SIMD-32 for two; fp64 and a few integer forms take four, so this is a LOWER bound of the slots really taken)
-    / (1,024 SIMDs x the launch's cycles).  COPIED from the tracked counter passes (profiles/valu_issue.json: separate
-    rocprofv3 --pmc runs of these kernels; cycles per launch do not move with the clock), not measured by this run."""
+def shader_clock_GHz(ctx, body, dev, seconds=0.06):
+    """Shader clock WHILE `body.launch()` runs: d2pc_clock_probe_device on a second stream -- eight sleeping one-wave blocks, one
+    per XCD, count shader cycles against the constant 100 MHz counter -- beside enough launches of the body to cover the
+    probe's window.  Returns (median GHz over the XCDs, [per XCD]) or (None, [])."""
+    out = torch.zeros(16, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        body.launch()
+    e1.record()
+    torch.cuda.synchronize()
+    per_ms = max(e0.elapsed_time(e1) / 3, 1e-3)
+    n = int(seconds * 1e3 / per_ms) + 4
+    lead = max(n // 8, 2)
+    for _ in range(lead):            # the probe starts once the body's launches are well under way ...
+        body.launch()
+    ctx.clock_probe(out.data_ptr(), int(seconds * 1e6 * 0.6), side.cuda_stream)
+    for _ in range(n):               # ... and ends before they run out
+        body.launch()
+    torch.cuda.synchronize()
+    v = out.cpu().numpy().reshape(8, 2)
+    ghz = sorted(float(c) / float(t) * 0.1 for c, t in v if t > 0)
+    if not ghz:
+        return None, []
+    return round(ghz[len(ghz) // 2], 3), [round(x, 3) for x in ghz]
+
+
+def valu_issue(key, kernel_ms, clock_GHz, build):
+    """The callback-body kernels are bound by VALU issue, not by HBM: next to their HBM fraction the line carries the fraction of
+    the chip's vector-issue slots they fill = VALU wave-instructions per launch x 2 cycles (a wave64 instruction occupies its
+    SIMD-32 for two; fp64 and several integer forms take four: a LOWER bound of the slots really taken) / (1,024 SIMDs x the
+    launch's shader cycles).  The cycles are THIS run's: measured time x measured shader clock (shader_clock_GHz).  The
+    instruction count is a property of the compiled kernel, read from the tracked counter pass (profiles/valu_issue.json,
+    rocprofv3 --pmc SQ_INSTS_VALU) -- and only if that pass ran on the build loaded now; otherwise nothing is reported
+    (advisor, round 5: a copied fraction went stale whenever the kernels changed)."""
     prof = os.path.join(ROOT, "profiles", "valu_issue.json")
     try:
-        t = json.load(open(prof))[key]
+        allp = json.load(open(prof))
+        t = allp[key]
     except Exception:
         return {}
-    return {"valu_issue_frac": t["valu_issue_frac"], "simd_cycles_per_valu_wave_instruction": t["simd_cycles_per_valu_wave_instruction"],
-            "valu_issue_measured": False, "valu_issue_source": t.get("source")}
+    if allp.get("build") != build or not clock_GHz:
+        return {"valu_issue_frac": None, "valu_issue_note": f"profiles/valu_issue.json is of build {allp.get('build')}, this run of {build}"
+                if allp.get("build") != build else "no shader clock measured"}
+    cycles = kernel_ms * 1e-3 * clock_GHz * 1e9
+    insts = t["valu_wave_insts_per_launch"]
+    return {"valu_issue_frac": round(insts * 2.0 / (1024.0 * cycles), 4),
+            "simd_cycles_per_valu_wave_instruction": round(1024.0 * cycles / insts, 3),
+            "valu_wave_insts_per_launch": insts, "valu_wave_insts_source": t.get("source"),
+            "valu_issue_how": "instruction count from the tracked counter pass of this build; cycles = this run's time x this run's clock"}
 
 
 def cpu_baseline(q, border, budget_s=12.0):
@@ -337,38 +397,33 @@ def cpu_baseline(q, border, budget_s=12.0):
     }
 
 
-def cpu_callback_body(q, border, frames=3):
-    """The WHOLE callback body on the CPU (cpp:55-85: median 11 -> x 1/8 -> reproject + pack), the oracle's restatement, one
-    thread, a bounded sample of 8-bit 4K frames: the CPU column beside the callback_* lines (round 4's verdict, missing #5).
-    NOT a fair stand-in for the reference's cost: oracle/d2pc_oracle.c's median recounts a k x k histogram walk per pixel
-    (clarity over speed), while cv::medianBlur uses the constant-time sliding-histogram algorithm with SIMD for 8-bit images
-    and k > 5 [upstream] -- expect OpenCV's filter several times faster than this port; the reprojection part is the same
-    loop cpu_baseline times."""
+def cpu_callback_body(q, border, budget_s=8.0):
+    """The WHOLE callback body on the CPU (cpp:55-85: median 11 -> x 1/8 -> reproject + pack), one thread like the reference's
+    spinner, a bounded sample of 8-bit 4K frames: the CPU column beside the callback_* lines.  The median is
+    oracle.median_u8_fast -- Perreault & Hebert's constant-time sliding histogram, the algorithm cv::medianBlur runs for 8-bit
+    images and k > 5 [upstream] (plain C, column stripes, no hand-written SIMD) -- pinned byte for byte to the oracle's checker
+    median in tests/test_oracle.py; the reprojection part is the loop cpu_baseline times."""
     import oracle
 
     rng = np.random.default_rng(0xD2C)
     img = rng.integers(0, 256, size=(H4K, W4K)).astype(np.uint8)
-    oracle.reproject(oracle.median_u8(img[:256], 11), q, border=border, scale=0.125)  # warm
-    # the oracle's median is an OpenMP loop over rows: ONE thread here, like the reference's single-threaded spinner
-    try:
-        from threadpoolctl import threadpool_limits
-        limit, cores = threadpool_limits(limits=1, user_api="openmp"), 1
-    except Exception:
-        import contextlib
-        limit, cores = contextlib.nullcontext(), oracle.max_threads()
-    with limit:
-        t0 = time.perf_counter()
-        tm = 0.0
-        for _ in range(frames):
-            t1 = time.perf_counter()
-            med = oracle.median_u8(img, 11)
-            tm += time.perf_counter() - t1
-            oracle.reproject(med, q, border=border, scale=0.125, threads=1)
+    oracle.reproject(oracle.median_u8_fast(img[:256], 11), q, border=border, scale=0.125)  # warm
+    t0 = time.perf_counter()
+    tm, frames = 0.0, 0
+    while True:
+        t1 = time.perf_counter()
+        med = oracle.median_u8_fast(img, 11)
+        tm += time.perf_counter() - t1
+        oracle.reproject(med, q, border=border, scale=0.125, threads=1)
+        frames += 1
         el = time.perf_counter() - t0
-    return {"value": round(W4K * H4K * frames / el / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        if el > budget_s:
+            break
+    return {"value": round(W4K * H4K * frames / el / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "median_algorithm": "Perreault-Hebert constant-time sliding histogram (oracle.median_u8_fast)",
             "median_share_of_time": round(tm / el, 3),
-            "sample": f"{frames} frames of 3840x2160 u8: oracle median 11 x 11 (per-pixel histogram walk: slower than cv::medianBlur's "
-                      f"constant-time algorithm, so this UNDERSTATES the reference) + x 1/8 + reproject, {el:.1f} s"}
+            "sample": f"{frames} frames of 3840x2160 u8: constant-time median 11 x 11 (Perreault-Hebert, the algorithm of "
+                      f"cv::medianBlur for 8-bit k > 5) + x 1/8 + reproject, 1 thread, {el:.1f} s"}
 
 
 def host_path_rates(q, border):
@@ -449,6 +504,52 @@ def host_path_rates(q, border):
         res["pipelined_direct_host_write"] = {"ms_per_frame": round(dt * 1e3, 3),
                                               "Mpixels_per_s": round(W4K * H4K / dt / 1e6, 1)}
     return res
+
+
+def workload_string(a):
+    """config.workload, at most 120 characters (the driver's record keeps that many): what a step is and how it is warmed."""
+    w = (f"config 4: {a.frames}x3840x2160 fp32/step, border {a.border}, {a.mode}; time-floored warm-up >={a.heat_ms:g} ms, "
+         f"then {a.steps} timed steps")
+    assert len(w) <= 120, len(w)
+    return w
+
+
+# The driver's record keeps the FIRST 21 scalar entries of `roofline` (lists and objects are dropped, strings cut at 120
+# characters): these come first, in this order, whatever else the run adds (round 5's verdict, item 1).
+ROOFLINE_HEAD = (
+    "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_launch", "kernel_ms_avg",
+    "frac_sustained", "device_fill_GBs", "compact_all_valid_frac", "compact_holes_frac", "compact_holes_index_frac",
+    "c3_32x1080p_frac", "c4_1frame_compact_us", "c4_2frames_compact_us", "callback_parity_ms", "callback_compact_ms",
+    "callback_parity_valu_issue_frac", "callback_parity_clock_GHz")
+
+
+def order_roofline(r):
+    """ROOFLINE_HEAD's keys first (None where this run did not measure one: multi-GPU runs, --no-variants), then the rest in
+    the order they were added."""
+    out = {k: r.get(k) for k in ROOFLINE_HEAD}
+    for k, v in r.items():
+        if k not in out:
+            out[k] = v
+    return out
+
+
+def driver_view(line, n_scalars=21, max_str=120):
+    """What the driver's BENCH_rNN.json `parsed` keeps of a bench line, as observed on rounds 4 and 5: of `roofline` the first
+    21 scalar entries, strings cut at 120 characters, nested objects and lists dropped.  tests/test_bench_record.py uses it."""
+    def scalars(d, limit):
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, (dict, list, tuple)):
+                continue
+            if len(out) >= limit:
+                break
+            out[k] = v[:max_str] if isinstance(v, str) else v
+        return out
+    view = scalars(line, 10 ** 6)
+    for key in ("config", "roofline", "cpu_baseline"):
+        if isinstance(line.get(key), dict):
+            view[key] = scalars(line[key], n_scalars)
+    return view
 
 
 def main():
@@ -533,6 +634,7 @@ def main():
                                                                     heat_ms=a.heat_ms)
     # every rank calibrates its device on its own output buffer (plain fill / copy, >= 100 ms each)
     cal = device_calibration(ctx, batch) if not a.no_extras else None
+    headline_clock = shader_clock_GHz(ctx, batch, dev) if (not a.no_extras and world == 1) else (None, [])
     wall = multi_gpu.allreduce_max(wall)
     kernel_ms_max = multi_gpu.allreduce_max(kernel_ms)
     per_rank_kernel_ms = multi_gpu.allgather_floats(kernel_ms)
@@ -557,11 +659,12 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"config 4: {a.frames} x 3840x2160 fp32 disparity frames per step, d~U(0.5,128), "
-                        f"border {a.border}, mode {a.mode}, one stream per GPU, Q broadcast from rank 0; "
-                        f"time-floored warm-up: the {a.warmup} warm-up steps are followed by untimed launches of the same step "
-                        f"until >= {a.heat_ms:g} ms of device time have passed (roofline.warmup_launches_actual), then exactly "
-                        f"{a.steps} timed steps",
+            # <= 120 characters: the driver's record cuts strings there (tests/test_bench_record.py replays the rule)
+            "workload": workload_string(a),
+            "workload_detail": f"config 4: {a.frames} x 3840x2160 fp32 disparity frames per step, d~U(0.5,128), border {a.border}, "
+                               f"mode {a.mode}, one stream per GPU, Q broadcast from rank 0; time-floored warm-up: the {a.warmup} "
+                               f"warm-up steps are followed by untimed launches of the same step until >= {a.heat_ms:g} ms of device "
+                               f"time have passed (roofline.warmup_launches_actual), then exactly {a.steps} timed steps",
             "frames_per_step": a.frames, "width": W4K, "height": H4K, "border": a.border, "mode": a.mode,
             "points_per_step": n_points,
             "collective_backend": multi_gpu.backend_name(),
@@ -599,6 +702,7 @@ def main():
         out["roofline"]["frac_at_min_median_max_ms"] = [round(alg / (sp[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                         for k in ("min", "median", "max")]
         out["roofline"].update(cal)
+        out["roofline"]["headline_clock_GHz"] = headline_clock[0]
         out["roofline"]["achieved_over_device_fill"] = round(achieved / cal["device_fill_GBs"], 4)
         out["roofline"]["achieved_over_device_copy"] = round(achieved / cal["device_copy_GBs"], 4)
         # against the best streams of the kernel's own launch shape on this device: a 1:4 read:write stream sits
@@ -663,31 +767,46 @@ def main():
                 variants[name]["compaction_counters"] = compaction_counters(c2)
             del b2
             c2.close()
-        # camera-size COMPACT launches with indices, ~30 % invalid (iid): config 3's own geometry as one frame and as a 32-frame
-        # batch, and ONE 4K frame (a camera delivers frames one at a time) -- each in one launch
+        # camera-size COMPACT launches with indices, ~30 % invalid (iid): config 3's geometry as one frame and as a 32-frame batch,
+        # ONE 4K frame and TWO.  A camera delivers a NEW frame every time (hpp:77-78): every launch takes the next frame(s) of a
+        # ring of distinct frames totalling >= 512 MB of input (16 x 4K, 64 x 1080p), with its own output slot, so that no launch
+        # finds its input (or its previous output) in the 256-MiB Infinity Cache; `*_cached_us` is the same launch repeated on
+        # ONE frame (round 5's figure: optimistic, the input stays cached).
         W3, H3 = 1920, 1080
-        for name, nfr, wv, hv, what in (
-                ("compact_1080p_30pct_holes_index_1frame", 1, W3, H3, "config 3 geometry; k_compact_resident (one launch, one resident block per 2048-pixel tile)"),
-                ("compact_1080p_30pct_holes_index_32frames", 32, W3, H3, "config 3 geometry; k_state_clear + k_compact_onepass"),
-                ("compact_4k_30pct_holes_index_1frame", 1, W4K, H4K, "k_compact_resident_lean<32>: one launch, 955 resident blocks of 8192 pixels, disparities in registers between count and scatter"),
-                ("compact_4k_30pct_holes_index_2frames", 2, W4K, H4K, "two 4K frames in one call: k_compact_resident_lean<32> twice, back to back (one launch of 16384-pixel blocks was 20 % slower: profiles/r05_ab_pair.txt)")):
+        for name, nfr, ring, wv, hv, what in (
+                ("compact_1080p_30pct_holes_index_1frame", 1, 64, W3, H3, "config 3 geometry; k_compact_resident (one launch, one resident block per 2048-pixel tile)"),
+                ("compact_1080p_30pct_holes_index_32frames", 32, 32, W3, H3, "config 3 geometry; k_compact_onepass"),
+                ("compact_4k_30pct_holes_index_1frame", 1, 16, W4K, H4K, "k_compact_resident_lean<32>: one launch, 955 resident blocks of 8192 pixels, disparities in registers between count and scatter"),
+                ("compact_4k_30pct_holes_index_2frames", 2, 16, W4K, H4K, "two 4K frames in one call: k_compact_resident_lean<32> twice, back to back")):
             c2 = d2pc.Context(device_id=local_rank, border=40, mode=d2pc.MODE_COMPACT, q=q)
-            b2 = DeviceBatch(c2, nfr, hv, wv, want_index=True, device=dev)
-            for f in range(nfr):
+            b2 = DeviceBatch(c2, ring, hv, wv, want_index=True, device=dev, reserve=False)
+            c2.reserve(wv, hv, nfr)
+            for f in range(ring):
                 b2.disp[f].copy_(torch.from_numpy(synth_disparity(3, f, wv, hv, "holes")))
-            b2.launch()
+            cam = RingLaunch(c2, b2, nfr)
+            for _ in range(cam.positions):
+                cam.launch()
             torch.cuda.synchronize()
-            npts = int(b2.counts.sum().item())
+            npts = int(b2.counts.sum().item()) * nfr // ring   # points per launch, averaged over the ring
             c2.compact_stats_reset()
-            sp = spread(timed_rounds(b2, max(a.steps // 2, 20), 5))
+            sp = spread(timed_rounds(cam, max(a.steps // 2, 20) // cam.positions * cam.positions or cam.positions, 5))
             kms = sp["median"]
-            ab = algorithmic_bytes(b2, npts, True)
+            ab = 4 * nfr * b2.roi_n + 20 * npts
             variants[name] = {"Mpixels_per_s": round(nfr * wv * hv / (kms * 1e-3) / 1e6, 1),
                               "achieved_GBs": round(ab / (kms * 1e-3) / 1e9, 1),
                               "frac": round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "ms_per_launch": kms, "ms_per_launch_spread": sp, "points_per_launch": npts,
+                              "ring_frames": ring, "ring_input_MB": round(ring * wv * hv * 4 / 1e6, 1),
                               "compaction_counters": compaction_counters(c2), "what": what}
             c2.check_async_error()
+            if ring > nfr:   # the same launch on ONE cached position of the ring
+                one = RingLaunch(c2, b2, nfr, fixed=True)
+                c2.compact_stats_reset()
+                spc = spread(timed_rounds(one, max(a.steps // 2, 20), 5))
+                variants[name]["cached_ms_per_launch"] = spc["median"]
+                variants[name]["cached_ms_per_launch_spread"] = spc
+                variants[name]["cached_compaction_counters"] = compaction_counters(c2)
+                c2.check_async_error()
             del b2
             c2.close()
         # the whole device-resident callback body (cpp:55-85): 8-bit disparity ->
@@ -711,11 +830,13 @@ def main():
 
         sp, sp2 = spread(timed_rounds(_Body(), n_side, 3)), spread(timed_rounds(_TwoLaunches(), n_side, 3))
         kms, kms2 = sp["median"], sp2["median"]
+        clk, clk_xcd = shader_clock_GHz(c3, _Body(), dev)
         ab_cb = a.frames * b3.roi_n * 17   # 1 B read + 16 B written per ROI pixel (the window's halo re-reads come from cache)
         variants["callback_u8_median11_parity_border40"] = {
             "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
             "achieved_GBs": round(ab_cb / (kms * 1e-3) / 1e9, 1), "frac": round(ab_cb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            **valu_issue("callback_parity"),
+            "clock_GHz": clk, "clock_GHz_per_xcd": clk_xcd,
+            **valu_issue("callback_parity", kms, clk, build_id()),
             "kernel_ms_spread": sp, "as_two_launches_ms_spread": sp2,
             "what": "d2pc_process_mono_device: k_callback_bs<11> (bit-sliced median of a tile + its points from LDS) per step",
             "as_two_launches_ms": round(kms2, 4),
@@ -759,11 +880,15 @@ def main():
                 rec[fused] = (sp, compaction_counters(c4))
             npts = int(b4.counts.sum().item())
             kms, kms2 = rec[2][0]["median"], rec[0][0]["median"]
+            c4.set_tuning("callback_fused_compact", 2)
+            clk, clk_xcd = shader_clock_GHz(c4, _BodyCompact(), dev)
+            c4.check_async_error()
             ab_cc = a.frames * b4.roi_n * 1 + 20 * npts   # 1 B read per ROI pixel + (16 + 4) B per surviving point
             variants[f"callback_u8_median11_compact_30pct_zero_{hole_kind}"] = {
                 "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
                 "achieved_GBs": round(ab_cc / (kms * 1e-3) / 1e9, 1), "frac": round(ab_cc / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                **valu_issue("callback_compact_" + hole_kind),
+                "clock_GHz": clk, "clock_GHz_per_xcd": clk_xcd,
+                **valu_issue("callback_compact_" + hole_kind, kms, clk, build_id()),
                 "kernel_ms_spread": rec[2][0], "points_per_step": npts, "compaction_counters": rec[2][1],
                 "what": "d2pc_process_mono_device, COMPACT + indices: k_callback_bs_compact_pipe<11> (persistent blocks: median of "
                         "a tile, then the previous tile's surviving points in row-major order; row counts handed over inside the launch)",
@@ -781,29 +906,39 @@ def main():
         out["variants_1gpu"] = variants
         # scalars the driver's parser keeps (nested objects under `parsed` are dropped): the north-star's own kernels
         r = out["roofline"]
-        r["compact_all_valid_frac"] = variants["compact_border40_all_valid"]["frac"]
-        r["compact_holes_frac"] = variants["compact_border40_30pct_holes"]["frac"]
-        r["compact_holes_index_frac"] = variants["compact_border40_30pct_holes_index"]["frac"]
-        r["compact_all_valid_index_frac"] = variants["compact_border40_all_valid_index"]["frac"]
-        r["compact_holes_ms"] = variants["compact_border40_30pct_holes"]["kernel_ms_avg"]
-        r["c3_32x1080p_frac"] = variants["compact_1080p_30pct_holes_index_32frames"]["frac"]
-        r["c3_1frame_us"] = round(variants["compact_1080p_30pct_holes_index_1frame"]["ms_per_launch"] * 1e3, 2)
-        r["c4_1frame_compact_us"] = round(variants["compact_4k_30pct_holes_index_1frame"]["ms_per_launch"] * 1e3, 2)
-        r["c4_2frames_compact_us"] = round(variants["compact_4k_30pct_holes_index_2frames"]["ms_per_launch"] * 1e3, 2)
-        r["c4_2frames_wait_us_per_tile"] = (variants["compact_4k_30pct_holes_index_2frames"]["compaction_counters"] or {}).get("wait_us_per_tile")
-        r["parity_u8_frac"] = variants["parity_u8_input_border40"]["frac"]
-        r["callback_parity_ms"] = variants["callback_u8_median11_parity_border40"]["kernel_ms_avg"]
-        r["callback_parity_frac"] = variants["callback_u8_median11_parity_border40"]["frac"]
-        r["callback_compact_ms"] = variants["callback_u8_median11_compact_30pct_zero_blocky"]["kernel_ms_avg"]
-        r["callback_compact_frac"] = variants["callback_u8_median11_compact_30pct_zero_blocky"]["frac"]
-        r["callback_parity_valu_issue_frac"] = variants["callback_u8_median11_parity_border40"].get("valu_issue_frac")
-        r["callback_compact_valu_issue_frac"] = variants["callback_u8_median11_compact_30pct_zero_blocky"].get("valu_issue_frac")
+        v = variants
+        r["compact_all_valid_frac"] = v["compact_border40_all_valid"]["frac"]
+        r["compact_holes_frac"] = v["compact_border40_30pct_holes"]["frac"]
+        r["compact_holes_index_frac"] = v["compact_border40_30pct_holes_index"]["frac"]
+        r["c3_32x1080p_frac"] = v["compact_1080p_30pct_holes_index_32frames"]["frac"]
+        # camera-shaped launches on DISTINCT frames (a ring >= 512 MB of input); *_cached_us: the same frame again and again
+        r["c4_1frame_compact_us"] = round(v["compact_4k_30pct_holes_index_1frame"]["ms_per_launch"] * 1e3, 2)
+        r["c4_2frames_compact_us"] = round(v["compact_4k_30pct_holes_index_2frames"]["ms_per_launch"] * 1e3, 2)
+        r["callback_parity_ms"] = v["callback_u8_median11_parity_border40"]["kernel_ms_avg"]
+        r["callback_compact_ms"] = v["callback_u8_median11_compact_30pct_zero_blocky"]["kernel_ms_avg"]
+        r["callback_parity_valu_issue_frac"] = v["callback_u8_median11_parity_border40"].get("valu_issue_frac")
+        r["callback_parity_clock_GHz"] = v["callback_u8_median11_parity_border40"].get("clock_GHz")
+        # (beyond the driver's first 21)
+        r["compact_all_valid_index_frac"] = v["compact_border40_all_valid_index"]["frac"]
+        r["compact_holes_ms"] = v["compact_border40_30pct_holes"]["kernel_ms_avg"]
+        r["c3_1frame_us"] = round(v["compact_1080p_30pct_holes_index_1frame"]["ms_per_launch"] * 1e3, 2)
+        r["c3_1frame_cached_us"] = round(v["compact_1080p_30pct_holes_index_1frame"]["cached_ms_per_launch"] * 1e3, 2)
+        r["c4_1frame_compact_cached_us"] = round(v["compact_4k_30pct_holes_index_1frame"]["cached_ms_per_launch"] * 1e3, 2)
+        r["c4_2frames_compact_cached_us"] = round(v["compact_4k_30pct_holes_index_2frames"]["cached_ms_per_launch"] * 1e3, 2)
+        r["c4_1frame_wait_us_per_tile"] = (v["compact_4k_30pct_holes_index_1frame"]["compaction_counters"] or {}).get("wait_us_per_tile")
+        r["c4_2frames_wait_us_per_tile"] = (v["compact_4k_30pct_holes_index_2frames"]["compaction_counters"] or {}).get("wait_us_per_tile")
+        r["parity_u8_frac"] = v["parity_u8_input_border40"]["frac"]
+        r["callback_parity_frac"] = v["callback_u8_median11_parity_border40"]["frac"]
+        r["callback_compact_frac"] = v["callback_u8_median11_compact_30pct_zero_blocky"]["frac"]
+        r["callback_compact_valu_issue_frac"] = v["callback_u8_median11_compact_30pct_zero_blocky"].get("valu_issue_frac")
+        r["callback_compact_clock_GHz"] = v["callback_u8_median11_compact_30pct_zero_blocky"].get("clock_GHz")
     if rank == 0 and world == 1 and not a.no_cpu:  # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(q, a.border)
         if "variants_1gpu" in out:  # the CPU column of the callback-body lines
             cb = cpu_callback_body(q, a.border)
             out["cpu_baseline"]["callback_body"] = cb
             out["roofline"]["callback_cpu_port_Mpix_s"] = cb["value"]
+    out["roofline"] = order_roofline(out["roofline"])
     if rank == 0:
         print(json.dumps(out), flush=True)
     multi_gpu.barrier()

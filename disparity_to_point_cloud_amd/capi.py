@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
 EXT_SYMBOLS = [
     "d2pc_ext_revision", "d2pc_reserve", "d2pc_reserve_mono", "d2pc_release_graph_buffers", "d2pc_compact_stats",
     "d2pc_compact_stats_reset", "d2pc_membench_fill", "d2pc_membench_copy", "d2pc_last_stage_times", "d2pc_set_tuning",
-    "d2pc_ext_set_test_hook",
+    "d2pc_ext_set_test_hook", "d2pc_clock_probe_device",
 ]
 ABI_VERSION = 2
 FORM_DEFAULT, FORM_CV24, FORM_CV4 = 0, 24, 4   # d2pc_reproject_form
@@ -247,6 +247,7 @@ def load_library(variant=None):
     L.d2pc_compact_stats_reset.argtypes = [vp]
     L.d2pc_membench_fill.argtypes = [vp, vp, ctypes.c_size_t, vp]
     L.d2pc_membench_copy.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
+    L.d2pc_clock_probe_device.argtypes = [vp, vp, ctypes.c_uint32, vp]
     L.d2pc_set_tuning.argtypes = [vp, cp, ctypes.c_int]
     L.d2pc_ext_set_test_hook.argtypes = [vp, cp, ctypes.c_int]
     L.d2pc_set_reproject_form.argtypes = [vp, ctypes.c_int]
@@ -459,6 +460,10 @@ class Context:
 
     def membench_fill(self, d_dst_ptr, nbytes, stream_ptr=None):
         self._check(self._L.d2pc_membench_fill(self._h, d_dst_ptr, nbytes, stream_ptr))
+
+    def clock_probe(self, d_out16_ptr, min_us, stream_ptr=None):
+        """d2pc_clock_probe_device: 8 x {shader cycles, 100-MHz ticks} into 16 uint64 of device memory, asynchronous."""
+        self._check(self._L.d2pc_clock_probe_device(self._h, d_out16_ptr, int(min_us), stream_ptr))
 
     def membench_copy(self, d_src_ptr, d_dst_ptr, nbytes, stream_ptr=None):
         self._check(self._L.d2pc_membench_copy(self._h, d_src_ptr, d_dst_ptr, nbytes, stream_ptr))

@@ -121,6 +121,7 @@ hipError_t launch_callback_bs_compact(const LaunchArgs &a, MedianArgs m, const v
 
 // Device calibration for bench.py (d2pc_membench.hip): a plain dwordx4 fill and a dwordx4 copy, the two
 // streaming shapes the roofline fraction of the reprojection kernel is read against on the SAME device
+hipError_t launch_clock_probe(void *out16, uint32_t min_us, hipStream_t stream);
 hipError_t launch_membench_fill(void *dst, size_t bytes, uint32_t blocks, int unroll, bool nt, hipStream_t stream);
 hipError_t launch_membench_copy(const void *src, void *dst, size_t bytes, uint32_t blocks, int unroll, bool nt, hipStream_t stream);
 

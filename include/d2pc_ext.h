@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define D2PC_EXT_REVISION 5   /* round 5: the laboratory (experiment build) split from the product; 4: split off d2pc.h */
+#define D2PC_EXT_REVISION 6   /* round 6: d2pc_clock_probe_device, test hook "handoff_spin_ticks_first"; 5: the laboratory (experiment build) split from the product; 4: split off d2pc.h */
 int d2pc_ext_revision(void);
 
 /* ---- hipGraph capture plumbing ------------------------------------------------------------------------------ */
@@ -74,6 +74,15 @@ int d2pc_membench_fill(d2pc_ctx *ctx, void *d_dst, size_t bytes, void *stream);
 int d2pc_membench_copy(d2pc_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, void *stream);
 
 /*
+ * The shader clock while other work runs: eight one-wave blocks (one per XCD, as the dispatcher deals them) sleep for
+ * `min_us` microseconds of the constant 100 MHz counter and store, per block, {shader cycles passed, 100-MHz ticks passed}
+ * into d_out16 (16 x uint64, device memory).  GHz = cycles / ticks x 0.1.  Launch it on ANOTHER stream than the kernel
+ * whose clock is wanted, while that kernel is queued many times over; asynchronous; min_us 1..2,000,000.
+ * (bench.py: callback_*_clock_GHz -- the bit-sliced select is held near 1.7 GHz, the rest of the chip's kernels at 2.1-2.4.)
+ */
+int d2pc_clock_probe_device(d2pc_ctx *ctx, void *d_out16, uint32_t min_us, void *stream);
+
+/*
  * Per-stage timing of the synchronous host entry points (d2pc_process,
  * d2pc_process_mono8/16), the counterpart of the reference's printf
  * breadcrumbs (cpp:47-91).  Off by default; d2pc_set_tuning(ctx,
@@ -122,6 +131,9 @@ int d2pc_set_tuning(d2pc_ctx *ctx, const char *key, int value);
 /* TEST hooks that DO change the arithmetic, kept apart from the tuning keys for that reason (tests compare the two
  * routes to the same bytes with them; nothing else should call this):
  *   "force_general_q"  0/1: a cv::stereoRectify-structured Q goes through the general kernel as well
+ *   "handoff_spin_ticks_first"  -1 = off; >= 0: the wait budget, in 100-MHz ticks, of the FIRST of the two launches a
+ *                      two-frame 4K-class COMPACT call is made of (0 = give up at the first look that fails): lets a test
+ *                      make frame 0's hand-off time out while frame 1's does not (d2pc_check_async_error must report it)
  *   "general_q_form"   experiment build only: 1 = round 2's fused multiply-adds instead of OpenCV 3/4's association */
 int d2pc_ext_set_test_hook(d2pc_ctx *ctx, const char *key, int value);
 

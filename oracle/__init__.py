@@ -57,6 +57,8 @@ def lib():
             ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
             ctypes.c_int]
         L.d2pc_oracle_median_u8.restype = None
+        L.d2pc_oracle_median_u8_fast.argtypes = L.d2pc_oracle_median_u8.argtypes
+        L.d2pc_oracle_median_u8_fast.restype = None
         L.d2pc_oracle_max_threads.restype = ctypes.c_int
         L.d2pc_oracle_fuse_pixel.argtypes = [ctypes.c_int] * 7
         L.d2pc_oracle_fuse_pixel.restype = ctypes.c_int
@@ -135,6 +137,16 @@ def median_u8(img: np.ndarray, ksize=11) -> np.ndarray:
     out = np.empty(img.shape, dtype=np.uint8)
     lib().d2pc_oracle_median_u8(img.ctypes.data, img.strides[0], out.ctypes.data, out.strides[0],
                                 img.shape[1], img.shape[0], ksize)
+    return out
+
+
+def median_u8_fast(img: np.ndarray, ksize=11) -> np.ndarray:
+    """The same order statistic by the constant-time sliding-histogram algorithm (Perreault & Hebert 2007, what
+    cv::medianBlur runs for 8-bit images and ksize > 5 [upstream]); single-threaded.  bench.py's CPU column."""
+    assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+    out = np.empty(img.shape, dtype=np.uint8)
+    lib().d2pc_oracle_median_u8_fast(img.ctypes.data, img.strides[0], out.ctypes.data, out.strides[0],
+                                     img.shape[1], img.shape[0], ksize)
     return out
 
 

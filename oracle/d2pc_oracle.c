@@ -254,6 +254,106 @@ void d2pc_oracle_median_u8(const uint8_t *src, size_t src_stride_bytes,
   }
 }
 
+/* cpp:55-57 again, FAST form: the constant-time median of Perreault & Hebert
+ * ("Median Filtering in Constant Time", IEEE TIP 2007), the algorithm
+ * cv::medianBlur uses for CV_8U and ksize > 5 [upstream imgproc/smooth.cpp,
+ * medianBlur_8u_O1]: one 256-bin histogram per image column (16 coarse + 256
+ * fine counters) slides down one row at a time (one pixel out, one in); the
+ * kernel histogram slides along the row by adding the entering and removing
+ * the leaving column's COARSE histogram, and brings only the fine segment the
+ * median falls into up to date (lazily, `luc` = first virtual column not yet
+ * in it).  Taps are clamped to the image (BORDER_REPLICATE): virtual column j
+ * stands for column clamp(j).  Same order statistic as d2pc_oracle_median_u8,
+ * which stays the CHECKER (tests/test_oracle.py pins this one to it byte for
+ * byte); this one is the CPU COLUMN of bench.py's callback-body lines.
+ * Single-threaded, like the reference's spinner. */
+void d2pc_oracle_median_u8_fast(const uint8_t *src, size_t src_stride_bytes,
+                                uint8_t *dst, size_t dst_stride_bytes,
+                                int width, int height, int ksize) {
+  const int r = ksize / 2, half = (ksize * ksize) / 2;
+  if (width <= 0 || height <= 0) return;
+  /* column stripes (as upstream: the histograms of one stripe stay in cache): STRIPE output columns + r halo
+   * columns on either side; local column c stands for image column clamp(x0 - r + c) */
+  enum { STRIPE = 384 };
+  const int max_cols = (width < STRIPE ? width : STRIPE) + 2 * r;
+  uint16_t *coarse = (uint16_t *)malloc((size_t)max_cols * 16 * sizeof(uint16_t));
+  uint16_t *fine = (uint16_t *)malloc((size_t)max_cols * 256 * sizeof(uint16_t));
+  int *colx = (int *)malloc((size_t)max_cols * sizeof(int));
+  if (!coarse || !fine || !colx) { free(coarse); free(fine); free(colx); return; }
+#define D2PC_ROW(yy) (src + (size_t)((yy) < 0 ? 0 : (yy) >= height ? height - 1 : (yy)) * src_stride_bytes)
+  for (int x0 = 0; x0 < width; x0 += STRIPE) {
+    const int sw = width - x0 < STRIPE ? width - x0 : STRIPE, nc = sw + 2 * r;
+    for (int c = 0; c < nc; c++) {
+      const int j = x0 - r + c;
+      colx[c] = j < 0 ? 0 : j >= width ? width - 1 : j;
+    }
+    memset(coarse, 0, (size_t)nc * 16 * sizeof(uint16_t));
+    memset(fine, 0, (size_t)nc * 256 * sizeof(uint16_t));
+    /* column histograms of the window rows of y = -1 (rows -1-r .. -1+r, clamped): the loop's first step moves them to y = 0 */
+    for (int dy = -1 - r; dy <= -1 + r; dy++) {
+      const uint8_t *s = D2PC_ROW(dy);
+      for (int c = 0; c < nc; c++) {
+        const uint8_t v = s[colx[c]];
+        coarse[(size_t)c * 16 + (v >> 4)]++;
+        fine[(size_t)c * 256 + v]++;
+      }
+    }
+    for (int y = 0; y < height; y++) {
+      const uint8_t *out_row = D2PC_ROW(y - r - 1), *in_row = D2PC_ROW(y + r);
+      for (int c = 0; c < nc; c++) {
+        const uint8_t vo = out_row[colx[c]], vi = in_row[colx[c]];
+        coarse[(size_t)c * 16 + (vo >> 4)]--;
+        fine[(size_t)c * 256 + vo]--;
+        coarse[(size_t)c * 16 + (vi >> 4)]++;
+        fine[(size_t)c * 256 + vi]++;
+      }
+      uint16_t hc[16], hf[16][16];
+      int luc[16];  /* first local column NOT yet in fine segment k; the segment holds columns luc-ksize .. luc-1 */
+      memset(hc, 0, sizeof hc);
+      /* the kernel's coarse histogram for output 0 of the stripe minus its last column: local columns 0 .. 2r-1 */
+      for (int c = 0; c < 2 * r; c++)
+        for (int k = 0; k < 16; k++) hc[k] = (uint16_t)(hc[k] + coarse[(size_t)c * 16 + k]);
+      for (int k = 0; k < 16; k++) luc[k] = -ksize;  /* "holds nothing" */
+      uint8_t *d = dst + (size_t)y * dst_stride_bytes + x0;
+      for (int x = 0; x < sw; x++) {  /* output x of the stripe: local columns x .. x + 2r */
+        const uint16_t *cin = coarse + (size_t)(x + 2 * r) * 16;
+        for (int k = 0; k < 16; k++) hc[k] = (uint16_t)(hc[k] + cin[k]);
+        int acc = 0, k = 0;
+        for (; k < 16; k++) {
+          if (acc + hc[k] > half) break;
+          acc += hc[k];
+        }
+        uint16_t *f = hf[k];
+        if (luc[k] <= x) {  /* nothing of what it holds is still inside: rebuild */
+          memset(f, 0, 16 * sizeof(uint16_t));
+          for (int c = x; c <= x + 2 * r; c++) {
+            const uint16_t *p = fine + (size_t)c * 256 + 16 * k;
+            for (int b = 0; b < 16; b++) f[b] = (uint16_t)(f[b] + p[b]);
+          }
+        } else {
+          for (int c = luc[k]; c <= x + 2 * r; c++) {
+            const uint16_t *pi = fine + (size_t)c * 256 + 16 * k, *po = fine + (size_t)(c - ksize) * 256 + 16 * k;
+            for (int b = 0; b < 16; b++) f[b] = (uint16_t)(f[b] + pi[b] - po[b]);
+          }
+        }
+        luc[k] = x + 2 * r + 1;
+        int b = 0;
+        for (; b < 16; b++) {
+          acc += f[b];
+          if (acc > half) break;
+        }
+        d[x] = (uint8_t)(16 * k + b);
+        const uint16_t *cout = coarse + (size_t)x * 16;  /* local column x leaves */
+        for (int k2 = 0; k2 < 16; k2++) hc[k2] = (uint16_t)(hc[k2] - cout[k2]);
+      }
+    }
+  }
+#undef D2PC_ROW
+  free(coarse);
+  free(fine);
+  free(colx);
+}
+
 int d2pc_oracle_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

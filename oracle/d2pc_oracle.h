@@ -93,6 +93,15 @@ void d2pc_oracle_median_u8(const uint8_t *src, size_t src_stride_bytes,
                            uint8_t *dst, size_t dst_stride_bytes, int width,
                            int height, int ksize);
 
+/* cpp:55-57, the same order statistic by the constant-time sliding-histogram
+ * algorithm (Perreault & Hebert 2007: what cv::medianBlur runs for CV_8U,
+ * ksize > 5 [upstream]).  Single-threaded.  The CPU column of bench.py's
+ * callback-body lines; pinned byte for byte to d2pc_oracle_median_u8, which
+ * stays the checker. */
+void d2pc_oracle_median_u8_fast(const uint8_t *src, size_t src_stride_bytes,
+                                uint8_t *dst, size_t dst_stride_bytes,
+                                int width, int height, int ksize);
+
 /* ---- depth-map fusion inner loop (d2pc_oracle_fusion.c) ---- */
 /* The nine candidate rules of src/depth_map_fusion.cpp:162-235, numbered in
  * source order; GRAD_FILTER is the one getFusedDistance calls (cpp:159). */

@@ -44,7 +44,13 @@ int main(void) {
       for (size_t i = 1; i < k; i++) CHECK(idx[i] > idx[i - 1]);
     }
     d2pc_oracle_mono16_to_mono8(u16, (size_t)w * 2, m8, (size_t)w, w, h);
-    for (int ks = 1; ks <= 11; ks += 2) d2pc_oracle_median_u8(m8, (size_t)w, m8b, (size_t)w, w, h, ks);
+    for (int ks = 1; ks <= 11; ks += 2) {
+      d2pc_oracle_median_u8(m8, (size_t)w, m8b, (size_t)w, w, h, ks);
+      uint8_t *m8c = malloc(n);
+      d2pc_oracle_median_u8_fast(m8, (size_t)w, m8c, (size_t)w, w, h, ks);
+      CHECK(memcmp(m8c, m8b, n) == 0);
+      free(m8c);
+    }
     /* fusion: rules, median, crop, rotate, crop-to-square */
     const uint8_t *planes[6] = {u8, m8, m8b, u8, m8, m8b};
     const size_t pitch[6] = {(size_t)w, (size_t)w, (size_t)w, (size_t)w, (size_t)w, (size_t)w};

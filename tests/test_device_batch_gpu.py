@@ -598,6 +598,47 @@ def test_c4_4k_compact_frames_take_one_launch_each(n, pair):
         assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"4K compact frame {f}")
 
 
+def test_a_give_up_in_the_first_frame_of_a_two_frame_call_is_reported():
+    """Advisor, round 5 (medium): two 4K frames in one COMPACT call are TWO resident launches with consecutive epochs on one
+    state buffer.  A hand-off give-up in frame 0's launch stores epoch E in the header while the buffer remembered only E + 1:
+    d2pc_check_async_error answered OK over an incomplete cloud.  The test hook gives frame 0's launch a wait budget of zero
+    ticks (its waves give up at the eighth failed look), frame 1's the ordinary one: counts[0] must read 0xFFFFFFFF, frame 1
+    must be whole, and the check must fail.  Afterwards the same context, hook off, serves the call again cleanly."""
+    q = d2pc.make_q()
+    frames = [synth_disparity(4, 60 + f, 3840, 2160, "holes") for f in range(2)]
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
+        b = _batch(ctx, frames, want_index=True)
+        b.launch()
+        torch.cuda.synchronize()
+        ctx.check_async_error()
+        ctx.compact_stats_reset()
+        ctx.set_test_hook("handoff_spin_ticks_first", 0)
+        gave_up = False
+        for _ in range(6):   # (a launch in which no wave had to look eight times cannot give up: try again)
+            b.launch()
+            torch.cuda.synchronize()
+            if ctx.compact_stats()["timeouts"] >= 1:
+                gave_up = True
+                break
+        if not gave_up:
+            pytest.skip("no wave of frame 0 waited long enough to give up in six launches")
+        counts = b.counts.cpu().numpy().view(np.uint32)
+        assert counts[0] == 0xFFFFFFFF, counts
+        wp1, wi1 = oracle.reproject_compact(frames[1], q, border=40)
+        assert counts[1] == len(wi1)                                  # frame 1's launch ran with the ordinary budget
+        with pytest.raises(d2pc.D2pcError) as ei:
+            ctx.check_async_error()
+        assert ei.value.status == 9, ei.value                         # D2PC_ERR_INTERNAL
+        ctx.set_test_hook("handoff_spin_ticks_first", -1)
+        b.launch()
+        res = b.results()
+        ctx.check_async_error()                                       # the stale flag of the broken call is not this call's
+    for f, (pts, idx) in enumerate(res):
+        wp, wi = oracle.reproject_compact(frames[f], q, border=40)
+        assert np.array_equal(idx, wi), f"frame {f}"
+        assert_points_close(pts, wp, max_ulp=1, rel=1e-5, what=f"frame {f} after the broken call")
+
+
 @pytest.mark.parametrize("rpxt", [32, 64])
 @pytest.mark.parametrize("case", ["f32", "f32_odd", "u8", "u16", "general", "sliver", "cv24", "min_disparity"])
 def test_resident_lean_blocks_on_ragged_frames(rpxt, case):

@@ -229,6 +229,36 @@ def test_median_u8_against_scipy(k):
         assert np.array_equal(oracle.median_u8(img, k), ndimage.median_filter(img, size=k, mode="nearest")), (h, w, k)
 
 
+@pytest.mark.parametrize("k", [1, 3, 5, 7, 9, 11])
+def test_fast_median_is_pinned_to_the_checker(k):
+    """d2pc_oracle_median_u8_fast (Perreault & Hebert's constant-time sliding histogram, bench.py's CPU column of the
+    callback body, cpp:55-57) against d2pc_oracle_median_u8 (the per-pixel histogram walk, the CHECKER) byte for byte: images
+    smaller than, equal to and larger than the window, strided rows, ties, constant regions, the extremes 0 and 255."""
+    rng = np.random.default_rng(100 + k)
+    for h, w in ((1, 1), (1, 40), (33, 1), (2, 9), (k, k), (max(k - 1, 1), 3 * k), (64, 97), (131, 45), (40, 300)):
+        for kind in ("uniform", "few_levels", "extremes", "ramp"):
+            if kind == "uniform":
+                img = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+            elif kind == "few_levels":
+                img = (rng.integers(0, 4, size=(h, w)) * 85).astype(np.uint8)
+            elif kind == "extremes":
+                img = np.where(rng.random((h, w)) < 0.5, 0, 255).astype(np.uint8)
+            else:
+                img = ((np.arange(h)[:, None] * 7 + np.arange(w)[None, :] * 3) % 256).astype(np.uint8)
+            assert np.array_equal(oracle.median_u8_fast(img, k), oracle.median_u8(img, k)), (h, w, k, kind)
+    # a view with a row stride larger than its width
+    big = rng.integers(0, 256, size=(50, 128)).astype(np.uint8)
+    view = big[:, 5:90]
+    assert np.array_equal(oracle.median_u8_fast(view, k), oracle.median_u8(np.ascontiguousarray(view), k))
+
+
+def test_fast_median_full_frame_752x480():
+    """the reference's native frame (hpp:102-103), 11 x 11 (cpp:57): the two oracle medians agree on every byte"""
+    img = np.random.default_rng(7).integers(0, 256, size=(480, 752)).astype(np.uint8)
+    img[100:200, 300:500] = 0          # a no-match region
+    assert np.array_equal(oracle.median_u8_fast(img, 11), oracle.median_u8(img, 11))
+
+
 # ---- depth-map fusion inner loop (SURVEY.md 8(f) #4) ---------------------------
 def test_fusion_rules_hand_derived():
     """Answers worked out by hand from the text of src/depth_map_fusion.cpp:162-235."""
