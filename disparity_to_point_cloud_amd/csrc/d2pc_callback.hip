@@ -20,7 +20,7 @@ namespace d2pc {
 //  * a wave stores 64 consecutive points per instruction (1 KiB), like the PARITY kernel.
 // --------------------------------------------------------------------------
 template <int KS, int QK>
-__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_callback_bs(
+__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(D2PC_BS_WAVES))) void k_callback_bs(
     const uint8_t *__restrict__ src, float4 *__restrict__ out, uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
     const MedianArgs ma, const Geom g, const QArg<QK> Q) {
   using S = MedianBsShape<KS>;
@@ -144,7 +144,7 @@ struct CbCompactState {
 };
 
 template <int KS, int QK>
-__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_callback_bs_compact(
+__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(D2PC_BS_WAVES))) void k_callback_bs_compact(
     const uint8_t *__restrict__ src, float4 *__restrict__ out, uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
     uint8_t *state, const MedianArgs ma, const Geom g, const QArg<QK> Q) {
   using S = MedianBsShape<KS>;
@@ -432,7 +432,7 @@ struct CbEarlyPlace {
 };
 
 template <int KS, int QK>
-__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_callback_bs_compact_pipe(
+__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(D2PC_BS_WAVES))) void k_callback_bs_compact_pipe(
     const uint8_t *__restrict__ src, float4 *__restrict__ out, uint32_t *__restrict__ out_index, uint32_t *__restrict__ counts,
     uint8_t *state, const MedianArgs ma, const Geom g, const QArg<QK> Q) {
   using S = MedianBsShape<KS>;

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(kBlock) void k_compact_resident(const uint8_t *__re
       if (spins == 0) w0 = __builtin_amdgcn_s_memrealtime();
       backoff(spins);
       ++spins;
-      if ((spins & 7u) == 0 && (__builtin_amdgcn_s_memrealtime() - w0 > uint64_t(g.spin_ticks) ||
+      // (a budget of ZERO ticks -- only the test hook "handoff_spin_ticks_first" sets it -- gives up at the first look that fails)
+      if (((spins & 7u) == 0 || g.spin_ticks == 0u) && (__builtin_amdgcn_s_memrealtime() - w0 > uint64_t(g.spin_ticks) ||
                                 __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)) {
         // the header's flag carries the epoch here (nothing zeroes it between launches)
         if (lane == 0 && __hip_atomic_exchange(&hdr->timeout, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
@@ -427,7 +428,8 @@ __global__ __launch_bounds__(kBlock) void k_compact_resident_lean(const uint8_t 
       if (spins == 0) w0 = __builtin_amdgcn_s_memrealtime();
       backoff(spins);
       ++spins;
-      if ((spins & 7u) == 0 && (__builtin_amdgcn_s_memrealtime() - w0 > uint64_t(g.spin_ticks) ||
+      // (a budget of ZERO ticks -- only the test hook "handoff_spin_ticks_first" sets it -- gives up at the first look that fails)
+      if (((spins & 7u) == 0 || g.spin_ticks == 0u) && (__builtin_amdgcn_s_memrealtime() - w0 > uint64_t(g.spin_ticks) ||
                                 __hip_atomic_load(&hdr->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)) {
         if (lane == 0 && __hip_atomic_exchange(&hdr->timeout, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
           atomicAdd(&stats->timeouts, 1ull);

@@ -6,7 +6,7 @@
 namespace d2pc {
 
 template <int KS>
-__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_median_bs_u8(
+__global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_waves_per_eu(D2PC_BS_WAVES))) void k_median_bs_u8(
     const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const MedianArgs a) {
   using S = MedianBsShape<KS>;
   __shared__ __attribute__((aligned(16))) uint32_t s_w[S::W_WORDS];

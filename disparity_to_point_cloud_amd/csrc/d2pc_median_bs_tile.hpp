@@ -33,6 +33,16 @@
 
 #include "d2pc_launch.hpp"
 
+// A/B switches (make variant NAME=x DEFS=-D...; tools/ab_callback.py): waves per SIMD the bit-sliced kernels are compiled for,
+// and how many of the window's rows keep their plane words in registers from the count pass to the candidate update (each
+// such row saves one LDS read of 12 words per plane and costs 12 registers: 3 waves per SIMD leave room for none)
+#ifndef D2PC_BS_WAVES
+#define D2PC_BS_WAVES 3
+#endif
+#ifndef D2PC_BS_KEEP_ROWS
+#define D2PC_BS_KEEP_ROWS 0
+#endif
+
 namespace d2pc {
 
 #ifdef D2PC_DIAG
@@ -204,6 +214,8 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
   uint32_t mm[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) mm[k] = ((127 - S::D0) >> k) & 1 ? 0xffffffffu : 0u;
+  constexpr int KEEP = D2PC_BS_KEEP_ROWS < KS ? D2PC_BS_KEEP_ROWS : KS;
+  uint32_t kept[KEEP > 0 ? KEEP : 1][NWORD];
 #pragma unroll 1
   for (int pl = 7; pl >= 0; --pl) {
     const uint32_t *wp = w_row + pl * S::PLANE_STRIDE;
@@ -212,10 +224,16 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
     for (int k = 0; k < 8; ++k) c.a[k] = k < 7 ? mm[k] : 0u, c.b[k] = 0u, c.n[k] = k < 7 ? 1 : 0;
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
-      uint32_t w[NWORD];
-      ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+      if (dy < KEEP) {
+        ld_row<KS>(wp + dy * S::ROW_STRIDE, kept[dy]);
 #pragma unroll
-      for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, cand[dy][dx] & w[dx + PAR]);
+        for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, cand[dy][dx] & kept[dy][dx + PAR]);
+      } else {
+        uint32_t w[NWORD];
+        ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, cand[dy][dx] & w[dx + PAR]);
+      }
     }
     uint32_t s[8];
     csa_finish(c, s);
@@ -229,10 +247,15 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
     // not by the LDS round trip -- a build without any LDS read in this loop takes the same time.)
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
-      uint32_t w[NWORD];
-      ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+      if (dy < KEEP) {
 #pragma unroll
-      for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = bitop3<0x48>(w[dx + PAR], cand[dy][dx], is0);  // cand & (w ^ is0)
+        for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = bitop3<0x48>(kept[dy][dx + PAR], cand[dy][dx], is0);
+      } else {
+        uint32_t w[NWORD];
+        ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = bitop3<0x48>(w[dx + PAR], cand[dy][dx], is0);  // cand & (w ^ is0)
+      }
     }
   }
 }

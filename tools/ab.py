@@ -40,6 +40,10 @@ def main():
     ap.add_argument("--forms", default="0", help="tuning reproject_form (0 per Q kind, 24 / 4: one OpenCV generation bit for bit)")
     ap.add_argument("--tunes", default="", help="alternatives separated by ';', each a comma-separated list of d2pc_set_tuning key=value (e.g. 'chunk_mb=96;chunk_mb=48,chunk_first_frames=1')")
     ap.add_argument("--dtype", default="f32", choices=["f32", "u8", "u16"], help="input sample type (u8 / u16: the fused cpp:61 decode, scale 1/8 and 1/64)")
+    ap.add_argument("--oextras", default="0", help="points ADDED to the output frame stride (several: A/B); 256 points = one 4-KiB page: "
+                                                   "do write fronts an exact multiple of 8 KiB apart collide in the memory system?")
+    ap.add_argument("--splits", default="1", help="sub-launches per step (several: A/B): the frames in `split` groups launched back to back, so "
+                                                  "only frames/split write fronts are live at a time")
     ap.add_argument("--w", type=int, default=3840)
     ap.add_argument("--h", type=int, default=2160)
     a = ap.parse_args()
@@ -64,7 +68,9 @@ def main():
     W, H, F = a.w, a.h, a.frames
     oaligns = [int(x) for x in a.oaligns.split(",")]
     ooffs = [int(x) for x in a.ooffs.split(",")]
-    max_stride = max((W * H + al - 1) // al * al for al in oaligns)
+    oextras = [int(x) for x in a.oextras.split(",")]
+    splits = [int(x) for x in a.splits.split(",")]
+    max_stride = max((W * H + al - 1) // al * al for al in oaligns) + max(oextras)
     pool = torch.empty((F * max_stride + max(ooffs) + 16, 4), dtype=torch.float32, device="cuda")
     ioffs = [int(x) for x in a.ioffs.split(",")]
     index = torch.empty((F * max_stride + max(ioffs) + 64,), dtype=torch.int32, device="cuda") if a.idx else None
@@ -72,19 +78,24 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     class Cand:
-        def __init__(self, ctx, oalign, ooff, ioff=0):
+        def __init__(self, ctx, oalign, ooff, ioff=0, oextra=0, split=1):
             self.ctx = ctx
-            self.stride = (W * H + oalign - 1) // oalign * oalign
+            self.split = split
+            self.stride = (W * H + oalign - 1) // oalign * oalign + oextra
             self.out_ptr = pool.data_ptr() + 16 * ooff
             self.idx_ptr = index.data_ptr() + 4 * ioff if index is not None else None
             ctx.reserve(W, H, F)
         def launch(self):
-            self.ctx.process_device(disp.data_ptr(), dcode, dscale, W, H, W * esize, W * H * esize, F, self.out_ptr,
-                                    self.idx_ptr, self.stride, counts.data_ptr(), stream)
+            n = F // self.split
+            for f0 in range(0, F, n):
+                self.ctx.process_device(disp.data_ptr() + f0 * W * H * esize, dcode, dscale, W, H, W * esize, W * H * esize, n,
+                                        self.out_ptr + 16 * f0 * self.stride,
+                                        self.idx_ptr + 4 * f0 * self.stride if self.idx_ptr is not None else None, self.stride,
+                                        counts.data_ptr() + 4 * f0, stream)
 
     for lib in a.libs.split(","):
         L = load_variant(lib)
-        for mode, border, pxt, bpc, nv, algo, oal, oof, form, tune, iof in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(","), oaligns, ooffs, a.forms.split(","), a.tunes.split(";"), ioffs):
+        for mode, border, pxt, bpc, nv, algo, oal, oof, form, tune, iof, oex, spl in itertools.product(a.modes.split(","), a.borders.split(","), a.pxts.split(","), a.bpcs.split(","), a.novecs.split(","), a.algos.split(","), oaligns, ooffs, a.forms.split(","), a.tunes.split(";"), ioffs, oextras, splits):
             m = d2pc.MODE_PARITY if mode == "parity" else d2pc.MODE_COMPACT
             ctx = capi.Context(q=capi.make_q(), border=int(border), mode=m, compact_algo=int(algo))
             if mode == "compact":
@@ -100,12 +111,12 @@ def main():
             for kv in filter(None, tune.split(",")):
                 k, v = kv.split("=")
                 ctx.set_tuning(k, int(v))
-            b = Cand(ctx, oal, oof, iof)
+            b = Cand(ctx, oal, oof, iof, oex, spl)
             b.launch(); torch.cuda.synchronize()
             npts = int(counts.sum().item())
             roi_n = capi.roi_points(W, H, int(border))
             alg = esize * F * roi_n + (20 if a.idx else 16) * npts
-            cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo} oalign={oal} ooff={oof} form={form} {tune}" + (f" ioff={iof}" if len(ioffs) > 1 else ""), b, alg, []))
+            cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo} oalign={oal} ooff={oof} form={form} {tune}" + (f" ioff={iof}" if len(ioffs) > 1 else "") + (f" oextra={oex}" if len(oextras) > 1 else "") + (f" split={spl}" if len(splits) > 1 else ""), b, alg, []))
     for r in range(a.rounds):
         for label, b, alg, ts in cands:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
