@@ -115,12 +115,14 @@ struct d2pc_ctx {
   int chunk_first_frames = 0;      // algo 4: frames of the first chunk (0 = an eighth of a chunk)
   int resident_unbounded = 0;      // algo 3: admit launches of more blocks than are resident at once (see enqueue)
   int general_q_form = 0;          // 0: OpenCV 3/4's association bit for bit; 1: fused multiply-adds (round 2's form)
-#else
-  static constexpr int big_batch_algo = 2, resident_unbounded = 0, general_q_form = 0;  // (the product: the single pass; bounded; OpenCV's association)
-#endif
+  // closed experiments (round 6: behind the experiment build; the product runs their measured defaults)
   int resident_stagger_pct = -1;   // algo 3, register-resident form: scale of the ramped start in % (0 = every block loads at once;
                                    // -1 = choose: 50 for one frame that fills the device, else 0)
   int resident_pair = 0;           // algo 3: 1 = two 4K-class frames in ONE launch of 16,384-pixel blocks (0: two launches of 8,192-pixel blocks)
+#else
+  static constexpr int big_batch_algo = 2, resident_unbounded = 0, general_q_form = 0;  // (the product: the single pass; bounded; OpenCV's association)
+  static constexpr int resident_stagger_pct = -1, resident_pair = 0;  // (ramp for one device-filling frame only; two 4K frames = two launches)
+#endif
   int resident_pxt = 0;            // algo 3: pixels per thread of its blocks (0 = choose: the ordinary tile if the launch fits, else 32, else 64)
   int spin_timeout_ms = int(kDefaultSpinMs);  // single pass: hand-off wait budget
   int force_general_q = 0;

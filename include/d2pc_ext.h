@@ -102,7 +102,7 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * the same bytes are produced.  Keys of the product library (libd2pc.so): "pxt_parity" (ROI pixels per thread of the
  * one-shot PARITY blocks: 1 or 2; 0 = choose per launch), "pxt_compact" (8), "blocks_per_cu" (grid = blocks_per_cu x CUs,
  * capped by the tile count; 1..4096), "onepass_blocks_per_cu" (persistent blocks per CU of the single pass; 0 = choose:
- * 3 for 4K-class frames, 4 below), "resident_pxt" / "resident_stagger_pct" (shape and ramped start of the one-launch
+ * 3 for 4K-class frames, 4 below), "resident_pxt" (shape of the one-launch
  * resident forms), "no_vec_rows", "fuse_rows" (rows per wave of d2pc_fuse_device: 0 = choose, else even 2..1024),
  * "stage_timing" (0/1, see d2pc_last_stage_times), "spin_timeout_ms" (1..40000: time budget of the in-launch hand-off
  * waits), "callback_chunks" (0..64 pipeline chunks of d2pc_process_mono_device; <= 1 = no overlap),
@@ -113,8 +113,10 @@ int d2pc_last_stage_times(d2pc_ctx *ctx, d2pc_stage_times *times);
  * "membench_nt" (0/1), "host_direct_read" (0/1, default 1: a pinned fp32 / 8-bit frame handed to d2pc_process /
  * d2pc_process_mono8 without a median is read by the reprojection in place, PARITY mode), "median_algo" (0 = choose
  * per launch, 1 = one pixel per thread, 2 = 32 pixels per thread, bit-sliced; the two give identical bytes),
- * "onepass_form" (0 = choose, 2 = the dense single pass: the only form of the product), "resident_pair" (two 4K-class
- * COMPACT frames in one call: 0 = one launch each (default), 1 = round 4's one launch of blocks twice the size).
+ * "onepass_form" (0 = choose, 2 = the dense single pass: the only form of the product).
+ * (Closed in round 6 and moved to the experiment build: "resident_pair" -- two 4K-class COMPACT frames in one call: 0 = one
+ * launch each (the product), 1 = round 4's one launch of blocks twice the size -- and "resident_stagger_pct", the scale of
+ * the resident blocks' ramped start: profiles/r04_ab_stagger.txt, r05_ab_pair.txt.)
  *
  * EXPERIMENT BUILD (libd2pc_exp.so = the same sources with -DD2PC_EXPERIMENTS=1, `make -C csrc exp`; what tests/ and
  * tools/ load to re-run recorded negatives; never shipped, never what INTEGRATION.md links).  It adds, and only it

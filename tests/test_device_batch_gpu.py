@@ -578,8 +578,9 @@ def test_c4_4k_compact_frames_take_one_launch_each(n, pair):
     "resident_pair" = 1, still there -- measured 20 % slower than the two on the driver's device)."""
     q = d2pc.make_q()
     frames = [synth_disparity(4, 30 + f, 3840, 2160, ["holes", "blocky"][f % 2]) for f in range(n)]
-    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT) as ctx:
-        ctx.set_tuning("resident_pair", pair)
+    with d2pc.Context(q=q, mode=d2pc.MODE_COMPACT, variant=variant_for(exp=bool(pair))) as ctx:
+        if pair:   # (a closed experiment: the key exists in the experiment build only since round 6)
+            ctx.set_tuning("resident_pair", pair)
         b = _batch(ctx, frames, want_index=True)
         ctx.compact_stats_reset()
         for _ in range(3):

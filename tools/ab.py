@@ -44,16 +44,19 @@ def main():
                                                    "do write fronts an exact multiple of 8 KiB apart collide in the memory system?")
     ap.add_argument("--splits", default="1", help="sub-launches per step (several: A/B): the frames in `split` groups launched back to back, so "
                                                   "only frames/split write fronts are live at a time")
+    ap.add_argument("--ring", type=int, default=1, help="camera-shaped launches: RING x frames distinct input frames (and output slots), every launch "
+                                                        "takes the next `frames` of them, so no launch finds its input in the Infinity Cache")
     ap.add_argument("--w", type=int, default=3840)
     ap.add_argument("--h", type=int, default=2160)
     a = ap.parse_args()
     from disparity_to_point_cloud_amd.torch_api import DeviceBatch
     import disparity_to_point_cloud_amd as d2pc
     g = torch.Generator(device="cuda").manual_seed(1)
-    disp = torch.rand((a.frames, a.h, a.w), generator=g, device="cuda") * 127.5 + 0.5
+    NF = a.frames * a.ring
+    disp = torch.rand((NF, a.h, a.w), generator=g, device="cuda") * 127.5 + 0.5
     dcode, dscale, esize = {"f32": (0, 1.0, 4), "u8": (1, 0.125, 1), "u16": (2, 1.0 / 64, 2)}[a.dtype]
     if a.holes > 0 and a.blocky:
-        m = (torch.rand((a.frames, (a.h + 63) // 64, (a.w + 63) // 64), generator=g, device="cuda") >= a.holes).float()
+        m = (torch.rand((NF, (a.h + 63) // 64, (a.w + 63) // 64), generator=g, device="cuda") >= a.holes).float()
         m = m.repeat_interleave(64, dim=1).repeat_interleave(64, dim=2)[:, :a.h, :a.w]
         disp.mul_(m)
     elif a.holes > 0:
@@ -71,23 +74,26 @@ def main():
     oextras = [int(x) for x in a.oextras.split(",")]
     splits = [int(x) for x in a.splits.split(",")]
     max_stride = max((W * H + al - 1) // al * al for al in oaligns) + max(oextras)
-    pool = torch.empty((F * max_stride + max(ooffs) + 16, 4), dtype=torch.float32, device="cuda")
+    pool = torch.empty((NF * max_stride + max(ooffs) + 16, 4), dtype=torch.float32, device="cuda")
     ioffs = [int(x) for x in a.ioffs.split(",")]
-    index = torch.empty((F * max_stride + max(ioffs) + 64,), dtype=torch.int32, device="cuda") if a.idx else None
-    counts = torch.zeros((F,), dtype=torch.int32, device="cuda")
+    index = torch.empty((NF * max_stride + max(ioffs) + 64,), dtype=torch.int32, device="cuda") if a.idx else None
+    counts = torch.zeros((NF,), dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     class Cand:
         def __init__(self, ctx, oalign, ooff, ioff=0, oextra=0, split=1):
             self.ctx = ctx
             self.split = split
+            self.pos = 0
             self.stride = (W * H + oalign - 1) // oalign * oalign + oextra
             self.out_ptr = pool.data_ptr() + 16 * ooff
             self.idx_ptr = index.data_ptr() + 4 * ioff if index is not None else None
             ctx.reserve(W, H, F)
         def launch(self):
             n = F // self.split
-            for f0 in range(0, F, n):
+            base = self.pos * F
+            self.pos = (self.pos + 1) % a.ring
+            for f0 in range(base, base + F, n):
                 self.ctx.process_device(disp.data_ptr() + f0 * W * H * esize, dcode, dscale, W, H, W * esize, W * H * esize, n,
                                         self.out_ptr + 16 * f0 * self.stride,
                                         self.idx_ptr + 4 * f0 * self.stride if self.idx_ptr is not None else None, self.stride,
@@ -113,7 +119,10 @@ def main():
                 ctx.set_tuning(k, int(v))
             b = Cand(ctx, oal, oof, iof, oex, spl)
             b.launch(); torch.cuda.synchronize()
-            npts = int(counts.sum().item())
+            for _ in range(a.ring - 1):
+                b.launch()
+            torch.cuda.synchronize()
+            npts = int(counts.sum().item()) // a.ring
             roi_n = capi.roi_points(W, H, int(border))
             alg = esize * F * roi_n + (20 if a.idx else 16) * npts
             cands.append((f"{lib:8s} {mode:7s} b={border:>2s} pxt={pxt:>2s} bpc={bpc:>2s} novec={nv} algo={algo} oalign={oal} ooff={oof} form={form} {tune}" + (f" ioff={iof}" if len(ioffs) > 1 else "") + (f" oextra={oex}" if len(oextras) > 1 else "") + (f" split={spl}" if len(splits) > 1 else ""), b, alg, []))
