@@ -1,5 +1,5 @@
 // d2pc_launch.hpp -- host-side launch interface between the C ABI
-// (d2pc_capi.hip) and the kernels (d2pc_parity / _compact / _onepass / _callback / _median* / _fusion .hip).
+// (d2pc_capi_*.hip, d2pc_ctx.hpp) and the kernels (d2pc_parity / _compact / _onepass / _callback / _median* / _fusion .hip).
 #pragma once
 
 #include <hip/hip_runtime.h>

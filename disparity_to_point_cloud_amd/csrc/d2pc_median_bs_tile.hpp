@@ -42,6 +42,9 @@
 #ifndef D2PC_BS_KEEP_ROWS
 #define D2PC_BS_KEEP_ROWS 0
 #endif
+#ifndef D2PC_BS_NO_LDS
+#define D2PC_BS_NO_LDS 0
+#endif
 
 namespace d2pc {
 
@@ -193,11 +196,17 @@ __device__ __forceinline__ uint2 ld_pair(const uint32_t *p) {
 // bits_out[plane * THREADS].
 template <int KS>
 __device__ __forceinline__ void ld_row(const uint32_t *p, uint32_t (&w)[2 * MedianBsShape<KS>::NREAD]) {
+#if D2PC_BS_NO_LDS  // ENERGY PROBE ONLY (wrong results): the select's instructions without its LDS reads -- whatever the registers hold
+#pragma unroll
+  for (int i = 0; i < 2 * MedianBsShape<KS>::NREAD; ++i) asm volatile("; no LDS read" : "=v"(w[i]));
+  (void)p;
+#else
 #pragma unroll
   for (int i = 0; i < MedianBsShape<KS>::NREAD; ++i) {
     const uint2 v = ld_pair(p + 2 * i);
     w[2 * i] = v.x, w[2 * i + 1] = v.y;
   }
+#endif
 }
 
 template <int KS, int PAR>

@@ -449,7 +449,7 @@ inline QArg<QK> make_qarg(const LaunchArgs &a);
 template <>
 inline QArg<QK_GENERAL> make_qarg<QK_GENERAL>(const LaunchArgs &a) {
   QArg<QK_GENERAL> r;
-  r.m = a.q;  // (form and, for form 2, the segment table are filled by the host: d2pc_capi.hip)
+  r.m = a.q;  // (form and, for form 2, the segment table are filled by the host: fill_q in d2pc_capi_context.hip)
   return r;
 }
 template <>
@@ -462,7 +462,7 @@ template <>
 inline QArg<QK_STEREO_CV24> make_qarg<QK_STEREO_CV24>(const LaunchArgs &a) {
   QArg<QK_STEREO_CV24> r;
   r.s = a.qs;
-  r.seg = a.q.seg;  // the running column sum as the host replayed it (fill_q in d2pc_capi.hip)
+  r.seg = a.q.seg;  // the running column sum as the host replayed it (fill_q in d2pc_capi_context.hip)
   return r;
 }
 template <>

@@ -156,6 +156,26 @@ def main():
                                 b3.counts.data_ptr(), s)
     run("callback body PARITY (k_callback_bs<11>)", body, 17 * F * b3.roi_n)
 
+    # the same body on a DISPARITY-LIKE batch (what a block matcher delivers: piecewise-smooth surfaces, a little noise, 64 x 64
+    # no-match blocks): a power-capped kernel's clock depends on how many bits toggle, and iid uniform bytes toggle the most
+    gen = torch.Generator(device=dev).manual_seed(0xD2E)
+    yy = torch.arange(H, device=dev, dtype=torch.float32)[None, :, None]
+    xx = torch.arange(W, device=dev, dtype=torch.float32)[None, None, :]
+    ff = torch.arange(F, device=dev, dtype=torch.float32)[:, None, None]
+    surf = 40.0 + 30.0 * torch.sin(xx / 517.0 + ff) * torch.cos(yy / 389.0) + 0.02 * xx + 0.03 * yy
+    steps = (torch.rand((F, (H + 127) // 128, (W + 127) // 128), device=dev, generator=gen) * 4).floor() * 24.0
+    surf = surf + steps.repeat_interleave(128, dim=1).repeat_interleave(128, dim=2)[:, :H, :W]
+    surf = surf + torch.randn((F, H, W), device=dev, generator=gen) * 1.5
+    smooth = surf.clamp(1, 255).to(torch.uint8)
+    holes = torch.rand((F, (H + 63) // 64, (W + 63) // 64), device=dev, generator=gen) < 0.1
+    smooth[holes.repeat_interleave(64, dim=1).repeat_interleave(64, dim=2)[:, :H, :W]] = 0
+    del surf, steps, holes
+
+    def body_smooth():
+        ctx.process_mono_device(smooth.data_ptr(), d2pc.DTYPE_U8, W, H, W, W * H, F, 11, 0.125, b3.points.data_ptr(), None, b3.stride,
+                                b3.counts.data_ptr(), s)
+    run("callback body PARITY, disparity-like frames", body_smooth, 17 * F * b3.roi_n)
+
     def med():
         ctx.median_roi_device(raw.data_ptr(), W, H, W, W * H, F, b3.disp.data_ptr(), W, W * H, 11, s)
     run("median 11 x 11 over the ROI (k_median_bs_u8)", med, 2 * F * b3.roi_n)
