@@ -104,7 +104,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import disparity_to_point_cloud_amd as d2pc  # noqa: E402
-from disparity_to_point_cloud_amd import multi_gpu  # noqa: E402
+from disparity_to_point_cloud_amd import multi_gpu, telemetry  # noqa: E402
 from disparity_to_point_cloud_amd.synth import synth_disparity  # noqa: E402
 from disparity_to_point_cloud_amd.torch_api import DeviceBatch  # noqa: E402
 
@@ -261,7 +261,12 @@ def device_calibration(ctx, batch):
         def launch(self):
             ctx.membench_copy(base, base + half, half, s)
 
-    f = spread(timed_rounds(_Fill(), 5))
+    # the persistent fill under a sampler of the computing card's sysfs telemetry (round 5's verdict, item 4a: what distinguishes a
+    # 5.0 from a 6.3 TB/s device?  profiles/r06_devclass.txt: nothing these readings show)
+    card = telemetry.find_card(pci_address=telemetry.torch_pci_address(torch.cuda.current_device()))
+    with telemetry.Sampler(card, 0.004) as smp:
+        f = spread(timed_rounds(_Fill(), 5))
+    tel, static = smp.summary(), telemetry.static_state(card)
     c = spread(timed_rounds(_Copy(), 5))
     out = {"device_fill_GBs": round(nbytes / (f["median"] * 1e-3) / 1e9, 1),
            "device_copy_GBs": round(2 * half / (c["median"] * 1e-3) / 1e9, 1),
@@ -271,6 +276,12 @@ def device_calibration(ctx, batch):
                                "device_fill / device_copy: persistent blocks, plain stores (the single pass's shape; "
                                "device classes differ by ~15 % on it); *_oneshot_*: one block per 4 KiB, one 16-byte "
                                "access per thread (the headline kernel's shape: the ceiling of a store stream here)"}
+    med = lambda k: (tel.get(k) or {}).get("median")
+    out.update({"device_fill_sclk_MHz": med("sclk_MHz"), "device_fill_mclk_MHz": med("mclk_MHz"), "device_fill_fclk_MHz": med("dpm_fclk_MHz"),
+                "device_fill_power_W": med("metrics_socket_power_W") or med("power_input_W"),
+                "device_power_cap_W": static.get("power1_cap_W"),
+                "device_partition": (static.get("current_compute_partition", "?") + "/" + static.get("current_memory_partition", "?")) if static else None,
+                "device_fill_telemetry": tel if card else "the computing card's sysfs node is not visible"})
     # the headline kernel's launch shape: one-shot blocks, plain and non-temporal
     ctx.set_tuning("membench_blocks_per_cu", 0)
     ctx.set_tuning("membench_unroll", 1)
@@ -315,12 +326,16 @@ def shader_clock_GHz(ctx, body, dev, seconds=0.06):
     per_ms = max(e0.elapsed_time(e1) / 3, 1e-3)
     n = int(seconds * 1e3 / per_ms) + 4
     lead = max(n // 8, 2)
-    for _ in range(lead):            # the probe starts once the body's launches are well under way ...
-        body.launch()
-    ctx.clock_probe(out.data_ptr(), int(seconds * 1e6 * 0.6), side.cuda_stream)
-    for _ in range(n):               # ... and ends before they run out
-        body.launch()
-    torch.cuda.synchronize()
+    card = telemetry.find_card(pci_address=telemetry.torch_pci_address(torch.cuda.current_device()))
+    with telemetry.Sampler(card, 0.004) as smp:   # socket power of the computing card while the body runs (the PARITY body: the 1,400 W cap)
+        for _ in range(lead):            # the probe starts once the body's launches are well under way ...
+            body.launch()
+        ctx.clock_probe(out.data_ptr(), int(seconds * 1e6 * 0.6), side.cuda_stream)
+        for _ in range(n):               # ... and ends before they run out
+            body.launch()
+        torch.cuda.synchronize()
+    tel = smp.summary()
+    shader_clock_GHz.last_power_W = ((tel.get("metrics_socket_power_W") or tel.get("power_input_W") or {}).get("max"))
     v = out.cpu().numpy().reshape(8, 2)
     ghz = sorted(float(c) / float(t) * 0.1 for c, t in v if t > 0)
     if not ghz:
@@ -835,7 +850,7 @@ def main():
         variants["callback_u8_median11_parity_border40"] = {
             "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
             "achieved_GBs": round(ab_cb / (kms * 1e-3) / 1e9, 1), "frac": round(ab_cb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "clock_GHz": clk, "clock_GHz_per_xcd": clk_xcd,
+            "clock_GHz": clk, "clock_GHz_per_xcd": clk_xcd, "socket_power_W_max": getattr(shader_clock_GHz, "last_power_W", None),
             **valu_issue("callback_parity", kms, clk, build_id()),
             "kernel_ms_spread": sp, "as_two_launches_ms_spread": sp2,
             "what": "d2pc_process_mono_device: k_callback_bs<11> (bit-sliced median of a tile + its points from LDS) per step",
@@ -932,6 +947,7 @@ def main():
         r["callback_compact_frac"] = v["callback_u8_median11_compact_30pct_zero_blocky"]["frac"]
         r["callback_compact_valu_issue_frac"] = v["callback_u8_median11_compact_30pct_zero_blocky"].get("valu_issue_frac")
         r["callback_compact_clock_GHz"] = v["callback_u8_median11_compact_30pct_zero_blocky"].get("clock_GHz")
+        r["callback_parity_socket_power_W"] = v["callback_u8_median11_parity_border40"].get("socket_power_W_max")
     if rank == 0 and world == 1 and not a.no_cpu:  # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(q, a.border)
         if "variants_1gpu" in out:  # the CPU column of the callback-body lines
