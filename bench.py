@@ -314,7 +314,8 @@ def compaction_counters(ctx):
 def shader_clock_GHz(ctx, body, dev, seconds=0.06):
     """Shader clock WHILE `body.launch()` runs: d2pc_clock_probe_device on a second stream -- eight sleeping one-wave blocks, one
     per XCD, count shader cycles against the constant 100 MHz counter -- beside enough launches of the body to cover the
-    probe's window.  Returns (median GHz over the XCDs, [per XCD]) or (None, [])."""
+    probe's window; the computing card's socket power is sampled meanwhile.  Returns (median GHz over the XCDs, [per XCD], highest
+    socket power sample in W) -- (None, [], power) if no block reported."""
     out = torch.zeros(16, dtype=torch.int64, device=dev)
     side = torch.cuda.Stream(device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -335,12 +336,12 @@ def shader_clock_GHz(ctx, body, dev, seconds=0.06):
             body.launch()
         torch.cuda.synchronize()
     tel = smp.summary()
-    shader_clock_GHz.last_power_W = ((tel.get("metrics_socket_power_W") or tel.get("power_input_W") or {}).get("max"))
+    power = (tel.get("metrics_socket_power_W") or tel.get("power_input_W") or {}).get("max")
     v = out.cpu().numpy().reshape(8, 2)
     ghz = sorted(float(c) / float(t) * 0.1 for c, t in v if t > 0)
     if not ghz:
-        return None, []
-    return round(ghz[len(ghz) // 2], 3), [round(x, 3) for x in ghz]
+        return None, [], power
+    return round(ghz[len(ghz) // 2], 3), [round(x, 3) for x in ghz], power
 
 
 def valu_issue(key, kernel_ms, clock_GHz, build):
@@ -649,7 +650,7 @@ def main():
                                                                     heat_ms=a.heat_ms)
     # every rank calibrates its device on its own output buffer (plain fill / copy, >= 100 ms each)
     cal = device_calibration(ctx, batch) if not a.no_extras else None
-    headline_clock = shader_clock_GHz(ctx, batch, dev) if (not a.no_extras and world == 1) else (None, [])
+    headline_clock = shader_clock_GHz(ctx, batch, dev) if (not a.no_extras and world == 1) else (None, [], None)
     wall = multi_gpu.allreduce_max(wall)
     kernel_ms_max = multi_gpu.allreduce_max(kernel_ms)
     per_rank_kernel_ms = multi_gpu.allgather_floats(kernel_ms)
@@ -718,6 +719,7 @@ def main():
                                                         for k in ("min", "median", "max")]
         out["roofline"].update(cal)
         out["roofline"]["headline_clock_GHz"] = headline_clock[0]
+        out["roofline"]["headline_socket_power_W"] = headline_clock[2]
         out["roofline"]["achieved_over_device_fill"] = round(achieved / cal["device_fill_GBs"], 4)
         out["roofline"]["achieved_over_device_copy"] = round(achieved / cal["device_copy_GBs"], 4)
         # against the best streams of the kernel's own launch shape on this device: a 1:4 read:write stream sits
@@ -845,12 +847,12 @@ def main():
 
         sp, sp2 = spread(timed_rounds(_Body(), n_side, 3)), spread(timed_rounds(_TwoLaunches(), n_side, 3))
         kms, kms2 = sp["median"], sp2["median"]
-        clk, clk_xcd = shader_clock_GHz(c3, _Body(), dev)
+        clk, clk_xcd, clk_power = shader_clock_GHz(c3, _Body(), dev)
         ab_cb = a.frames * b3.roi_n * 17   # 1 B read + 16 B written per ROI pixel (the window's halo re-reads come from cache)
         variants["callback_u8_median11_parity_border40"] = {
             "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
             "achieved_GBs": round(ab_cb / (kms * 1e-3) / 1e9, 1), "frac": round(ab_cb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "clock_GHz": clk, "clock_GHz_per_xcd": clk_xcd, "socket_power_W_max": getattr(shader_clock_GHz, "last_power_W", None),
+            "clock_GHz": clk, "clock_GHz_per_xcd": clk_xcd, "socket_power_W_max": clk_power,
             **valu_issue("callback_parity", kms, clk, build_id()),
             "kernel_ms_spread": sp, "as_two_launches_ms_spread": sp2,
             "what": "d2pc_process_mono_device: k_callback_bs<11> (bit-sliced median of a tile + its points from LDS) per step",
@@ -896,13 +898,13 @@ def main():
             npts = int(b4.counts.sum().item())
             kms, kms2 = rec[2][0]["median"], rec[0][0]["median"]
             c4.set_tuning("callback_fused_compact", 2)
-            clk, clk_xcd = shader_clock_GHz(c4, _BodyCompact(), dev)
+            clk, clk_xcd, clk_power = shader_clock_GHz(c4, _BodyCompact(), dev)
             c4.check_async_error()
             ab_cc = a.frames * b4.roi_n * 1 + 20 * npts   # 1 B read per ROI pixel + (16 + 4) B per surviving point
             variants[f"callback_u8_median11_compact_30pct_zero_{hole_kind}"] = {
                 "Mpixels_per_s": round(pixels_per_step / (kms * 1e-3) / 1e6, 1), "kernel_ms_avg": kms,
                 "achieved_GBs": round(ab_cc / (kms * 1e-3) / 1e9, 1), "frac": round(ab_cc / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "clock_GHz": clk, "clock_GHz_per_xcd": clk_xcd,
+                "clock_GHz": clk, "clock_GHz_per_xcd": clk_xcd, "socket_power_W_max": clk_power,
                 **valu_issue("callback_compact_" + hole_kind, kms, clk, build_id()),
                 "kernel_ms_spread": rec[2][0], "points_per_step": npts, "compaction_counters": rec[2][1],
                 "what": "d2pc_process_mono_device, COMPACT + indices: k_callback_bs_compact_pipe<11> (persistent blocks: median of "

@@ -74,7 +74,7 @@ def _dpm_current(text):
 
 
 def parse_gpu_metrics(blob):
-    """gpu_metrics of the MI300 family (format 1, content revision 4-7): the header, then fixed-width little-endian fields.
+    """gpu_metrics of the MI300 / MI350 family (format 1, content revision 4-8; MI355X reports 1.8, 3,872 bytes): the header, then fixed-width little-endian fields.
     Only the leading fields whose layout is the same in every one of these revisions are decoded:
         u16 temperature_hotspot, temperature_mem, temperature_vrsoc, curr_socket_power (W), average_gfx_activity,
         average_umc_activity
