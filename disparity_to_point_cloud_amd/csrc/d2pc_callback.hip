@@ -3,6 +3,15 @@
 #include "d2pc_compact_common.hpp"
 #include "d2pc_median_bs_tile.hpp"
 
+// OCCUPANCY PROBE (make variant NAME=occ2 DEFS=-DD2PC_CB_LDS_PAD=20000): unused dynamic LDS per block of the PARITY body, so that
+// two blocks (or one) fit a CU instead of three -- how does a kernel at the socket power cap answer to fewer waves?
+// (profiles/r06_energy_probe.txt)
+#ifndef D2PC_CB_LDS_PAD
+#define D2PC_CB_LDS_PAD 0
+#endif
+
+
+
 namespace d2pc {
 
 // --------------------------------------------------------------------------
@@ -39,6 +48,8 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
   median_bs_tile<KS>(src + uint64_t(f) * ma.src_frame_stride, ma, int(x0), int(y0), s_w, s_raw, tid);
   D2PC_BS_STAMP(e0);
 
+  // (round 6: the table in 3 KB of its own, filled under the tile's loads instead of here behind a barrier: no difference --
+  //  562.7 against 562.5 us, profiles/r06_ab_callback_prio.txt; under the power cap a shorter stage buys nothing by itself)
   double *lut_iw = reinterpret_cast<double *>(s_raw);              // [256]
   float *lut_z = reinterpret_cast<float *>(s_raw) + 2 * 256;       // [256]
   static_assert(S::RAW_WORDS >= 3 * 256, "the table fits where the staged rows were");
@@ -63,7 +74,10 @@ __global__ __launch_bounds__(MedianBsShape<KS>::THREADS) __attribute__((amdgpu_w
   }
   const uint32_t r_end = y_end - y0 < uint32_t(S::TH) ? y_end - y0 : uint32_t(S::TH);  // rows of the tile inside the ROI
   // (two or four rows per trip, so that their chains LDS byte -> table entry -> fp64 products -> store overlap: no difference,
-  // 578.9 / 578.8 / 579.4 us per 16 x 4K; the epilogue is 13 % of a block's cycles and store-issue-bound: profiles/r05_callback_phases.txt)
+  // 578.9 / 578.8 / 579.4 us per 16 x 4K; the epilogue is 13 % of a block's cycles and store-issue-bound: profiles/r05_callback_phases.txt.
+  // Round 6, by hand what the compiler does not do -- it emits four serial chains per row, each under an exec mask of its own: the
+  // next row's bytes requested a trip ahead, the row's eight table reads in flight together, only the stores under the edge test:
+  // 584.5 against 583.2 us, nothing either: profiles/r06_ab_callback_prio.txt)
 #pragma unroll 1
   for (uint32_t r = wave; r < r_end; r += uint32_t(S::THREADS / 64)) {  // a wave takes every fourth row
     const uint32_t y = y0 + r;
@@ -827,7 +841,7 @@ hipError_t launch_callback_bs(const LaunchArgs &a, MedianArgs m, const void *src
   const uint8_t *s8 = static_cast<const uint8_t *>(src);
   float4 *o = static_cast<float4 *>(a.out_points);
 #define D2PC_CB_BS(KS, QK)                                                                                              \
-  hipLaunchKernelGGL((k_callback_bs<KS, QK>), dim3(uint32_t(blocks)), dim3(S::THREADS), 0, a.stream, s8, o, a.out_index, \
+  hipLaunchKernelGGL((k_callback_bs<KS, QK>), dim3(uint32_t(blocks)), dim3(S::THREADS), D2PC_CB_LDS_PAD, a.stream, s8, o, a.out_index, \
                      a.counts, m, a.geom, make_qarg<QK>(a))
   if (a.q_kind < QK_GENERAL || a.q_kind > QK_STEREO_CV4) return hipErrorInvalidValue;
   switch (ksize * 4 + a.q_kind) {

@@ -45,6 +45,21 @@
 #ifndef D2PC_BS_NO_LDS
 #define D2PC_BS_NO_LDS 0
 #endif
+// D2PC_BS_PRIO = 1 (the product since round 6): the stages AROUND the select (staging, plane words, bytes back, the callers' count /
+// scatter / epilogue stages) run at a raised wave priority (s_setprio 3), the select at the default.  A SIMD arbitrates vector issue
+// between its waves by priority, then age: the few, latency-bound instructions of those stages used to queue behind the co-resident
+// blocks' select streams (the plane-word stage took 8,200 cycles for ~260 instructions per thread); ahead of them the stages end
+// sooner, more of a block's life is select, and the chip -- at its socket power cap under this kernel -- runs a little wider and
+// slower: PARITY body 586.7 -> 573.0 us (2.06 -> 2.00 GHz), the bare median kernel 448 -> 433 us, the COMPACT bodies 678 -> 642 /
+// 715 -> 689 us, interleaved on one device (profiles/r06_ab_callback_prio.txt).  0 = everything at the default priority.
+#ifndef D2PC_BS_PRIO
+#define D2PC_BS_PRIO 1
+#endif
+#if D2PC_BS_PRIO
+#define D2PC_BS_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define D2PC_BS_SETPRIO(p)
+#endif
 
 namespace d2pc {
 
@@ -413,6 +428,7 @@ __device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows
   using S = MedianBsShape<KS>;
   using RW = MedianBsRows<KS>;
   D2PC_BS_STAMP(d0);
+  D2PC_BS_SETPRIO(3);
 #pragma unroll
   for (int k = 0; k < RW::PER_THREAD; ++k) {
     const uint32_t c = tid + uint32_t(k * S::THREADS);
@@ -451,10 +467,12 @@ __device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows
   const uint32_t wave = tid >> 6, lane = tid & 63u;
   const uint32_t par = wave & 1u, t = 2u * (lane & 3u) + par, row = 16u * (wave >> 1) + (lane >> 2);
   {
+    D2PC_BS_SETPRIO(0);
     const uint32_t *w_row = s_w + row * uint32_t(S::ROW_STRIDE) + (t - par);
     uint32_t *bits_out = s_raw + tid;  // the staged bytes are no longer needed
     if (par) bs::select<KS, 1>(w_row, bits_out);
     else bs::select<KS, 0>(w_row, bits_out);
+    D2PC_BS_SETPRIO(3);
   }
   __syncthreads();  // every wave has finished reading W
   D2PC_BS_STAMP(d3);

@@ -17,6 +17,9 @@
 #ifndef D2PC_DENSE_LAND_LATE
 #define D2PC_DENSE_LAND_LATE 0
 #endif
+#ifndef D2PC_ONEPASS_CTL_PRIO
+#define D2PC_ONEPASS_CTL_PRIO 0
+#endif
 
 namespace d2pc {
 // --------------------------------------------------------------------------
@@ -260,6 +263,9 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_compact_onepass_dense(const u
   __shared__ uint32_t s_stat[3];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool ctl = wave == uint32_t(NW);  // the last wave
+#if D2PC_ONEPASS_CTL_PRIO
+  if (ctl) __builtin_amdgcn_s_setprio(3);  // (A/B, round 6: the control wave's few instructions ahead of the workers' on its SIMD)
+#endif
   StateHeader *hdr = reinterpret_cast<StateHeader *>(state);
   PollStats polls{s_stat};
   if (tid < 3) s_stat[tid] = 0;
