@@ -279,7 +279,11 @@ void d2pc_oracle_median_u8_fast(const uint8_t *src, size_t src_stride_bytes,
   uint16_t *coarse = (uint16_t *)malloc((size_t)max_cols * 16 * sizeof(uint16_t));
   uint16_t *fine = (uint16_t *)malloc((size_t)max_cols * 256 * sizeof(uint16_t));
   int *colx = (int *)malloc((size_t)max_cols * sizeof(int));
-  if (!coarse || !fine || !colx) { free(coarse); free(fine); free(colx); return; }
+  if (!coarse || !fine || !colx) {  /* out of memory: the checker's algorithm needs none and gives the same bytes */
+    free(coarse); free(fine); free(colx);
+    d2pc_oracle_median_u8(src, src_stride_bytes, dst, dst_stride_bytes, width, height, ksize);
+    return;
+  }
 #define D2PC_ROW(yy) (src + (size_t)((yy) < 0 ? 0 : (yy) >= height ? height - 1 : (yy)) * src_stride_bytes)
   for (int x0 = 0; x0 < width; x0 += STRIPE) {
     const int sw = width - x0 < STRIPE ? width - x0 : STRIPE, nc = sw + 2 * r;
