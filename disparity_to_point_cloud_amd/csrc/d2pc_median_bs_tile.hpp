@@ -45,6 +45,9 @@
 #ifndef D2PC_BS_NO_LDS
 #define D2PC_BS_NO_LDS 0
 #endif
+#ifndef D2PC_BS_PEEL_MSB
+#define D2PC_BS_PEEL_MSB 1
+#endif
 // D2PC_BS_PRIO = 1 (the product since round 6): the stages AROUND the select (staging, plane words, bytes back, the callers' count /
 // scatter / epilogue stages) run at a raised wave priority (s_setprio 3), the select at the default.  A SIMD arbitrates vector issue
 // between its waves by priority, then age: the few, latency-bound instructions of those stages used to queue behind the co-resident
@@ -229,19 +232,53 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
   using S = MedianBsShape<KS>;
   constexpr int NWORD = 2 * S::NREAD;
   uint32_t cand[KS][KS];
-#pragma unroll
-  for (int dy = 0; dy < KS; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = 0xffffffffu;
-  // mm = 127 - d as seven words (d = candidates above the median): count + mm >= 128  <=>  count > d  <=>
+  // mm = 127 - d as seven words (d = candidates above the median at the start): count + mm >= 128  <=>  count > d  <=>
   // the median's bit is 1; otherwise d becomes d - count, i.e. mm becomes the sum's low seven digits.
   uint32_t mm[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) mm[k] = ((127 - S::D0) >> k) & 1 ? 0xffffffffu : 0u;
   constexpr int KEEP = D2PC_BS_KEEP_ROWS < KS ? D2PC_BS_KEEP_ROWS : KS;
   uint32_t kept[KEEP > 0 ? KEEP : 1][NWORD];
+#if D2PC_BS_PEEL_MSB
+  // The MOST SIGNIFICANT plane on its own (round 6): every tap is still a candidate, so its count needs no AND with the candidate
+  // words, its update is one XOR that CREATES them (cand = w ^ is0), and the k*k moves that used to set them to all-ones are gone:
+  // 2 k*k instructions fewer per thread and tile (242 of ~4,800 at 11 x 11; under the power cap operations pay linearly).
+  {
+    const uint32_t *wp = w_row + 7 * S::PLANE_STRIDE;
+    Csa c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.a[k] = k < 7 ? mm[k] : 0u, c.b[k] = 0u, c.n[k] = k < 7 ? 1 : 0;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      uint32_t w[NWORD];
+      ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, w[dx + PAR]);
+    }
+    uint32_t s[8];
+    csa_finish(c, s);
+    bits_out[7 * S::THREADS] = s[7];
+    const uint32_t is0 = ~s[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) mm[k] = bitop3<0xca>(is0, s[k], mm[k]);  // is0 ? s : mm
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      uint32_t w[NWORD];
+      ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = w[dx + PAR] ^ is0;
+    }
+  }
+  constexpr int kFirstPlane = 6;
+#else
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = 0xffffffffu;
+  constexpr int kFirstPlane = 7;
+#endif
 #pragma unroll 1
-  for (int pl = 7; pl >= 0; --pl) {
+  for (int pl = kFirstPlane; pl >= 0; --pl) {
     const uint32_t *wp = w_row + pl * S::PLANE_STRIDE;
     Csa c;
 #pragma unroll
