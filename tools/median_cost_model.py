@@ -56,6 +56,13 @@ def product_select():
     return total, per_plane
 
 
+def product_select_peeled():
+    """since round 6 (D2PC_BS_PEEL_MSB): in the most significant plane every tap is a candidate -- no AND in its count, its update is the
+    XOR that creates the candidate words, and the k*k moves that set them to all-ones (not counted in product_select) are gone"""
+    total, per_plane = product_select()
+    return total - N, total + N
+
+
 # ---------------------------------------------------------------- B: comparator networks
 def oddeven_merge(lo_wires, hi_wires):
     """Batcher's odd-even merge of two sorted wire lists (any lengths): comparators as (a, b) = (min wire, max wire)."""
@@ -253,6 +260,9 @@ def main():
     print("# 2-cycle class -- v_and, v_xor, v_bitop3 -- is one slot per lane; the 4-cycle class -- v_pk_min/max_u16, v_max_u32 -- two)")
     print(f"A  product, bit-sliced radix select: {per_plane} instructions per plane and 32 pixels, {tot} per 32 pixels"
           f" = {tot / px:.1f} slots / pixel   [measured: 300.9 M VALU wave-instructions per 16 x 4K launch = 154 / pixel incl. the other stages]")
+    peeled, before = product_select_peeled()
+    print(f"   with the {N} moves that initialise the candidate words: {before} = {before / px:.1f}; since the most significant plane is peeled off (round 6): "
+          f"{peeled} = {peeled / px:.1f} slots / pixel   [measured: 284.9 M per launch = 146 / pixel]")
     cs = column_sort_shared()
     print(f"\nB  sorted columns + pruned merges.  Column sort, shared vertically in pairs: {cs:.1f} comparators per pixel (x halo)")
     ce_pk = 2 * 2 / 2.0      # min + max, 4-cycle class (2 slots each), two pixels per instruction
