@@ -48,6 +48,9 @@
 #ifndef D2PC_BS_PEEL_MSB
 #define D2PC_BS_PEEL_MSB 1
 #endif
+#ifndef D2PC_BS_TRIM_READS
+#define D2PC_BS_TRIM_READS 1
+#endif
 // D2PC_BS_PRIO = 1 (the product since round 6): the stages AROUND the select (staging, plane words, bytes back, the callers' count /
 // scatter / epilogue stages) run at a raised wave priority (s_setprio 3), the select at the default.  A SIMD arbitrates vector issue
 // between its waves by priority, then age: the few, latency-bound instructions of those stages used to queue behind the co-resident
@@ -212,17 +215,27 @@ __device__ __forceinline__ uint2 ld_pair(const uint32_t *p) {
 // The select of one thread: 32 pixels of output row `row`, columns 8 j + t.  `w_row` points at word (t & ~1)
 // of plane 0, input row `row` (the window's first row).  Returns nothing: the median's bit planes go to
 // bits_out[plane * THREADS].
-template <int KS>
+// PAR >= 0 (the select: which of the NREAD aligned pairs' 2 NREAD words it uses is known: [PAR, PAR + KS)): the pair whose other half
+// is never used is read as ONE word -- 11 dwords per row instead of 12 at 11 x 11.  The select's LDS reads are 28 % of the callback
+// body's power (profiles/r06_energy_probe.txt).  PAR < 0: all pairs whole.
+template <int KS, int PAR = -1>
 __device__ __forceinline__ void ld_row(const uint32_t *p, uint32_t (&w)[2 * MedianBsShape<KS>::NREAD]) {
 #if D2PC_BS_NO_LDS  // ENERGY PROBE ONLY (wrong results): the select's instructions without its LDS reads -- whatever the registers hold
 #pragma unroll
   for (int i = 0; i < 2 * MedianBsShape<KS>::NREAD; ++i) asm volatile("; no LDS read" : "=v"(w[i]));
   (void)p;
 #else
+  constexpr int NR = MedianBsShape<KS>::NREAD;
 #pragma unroll
-  for (int i = 0; i < MedianBsShape<KS>::NREAD; ++i) {
-    const uint2 v = ld_pair(p + 2 * i);
-    w[2 * i] = v.x, w[2 * i + 1] = v.y;
+  for (int i = 0; i < NR; ++i) {
+    const bool lo_used = PAR < 0 || (2 * i >= PAR && 2 * i < PAR + KS), hi_used = PAR < 0 || (2 * i + 1 >= PAR && 2 * i + 1 < PAR + KS);
+    if (D2PC_BS_TRIM_READS && lo_used != hi_used) {
+      typedef const volatile __attribute__((address_space(3))) uint32_t *lds_u32;
+      w[2 * i + (hi_used ? 1 : 0)] = *(lds_u32)(p + 2 * i + (hi_used ? 1 : 0));
+    } else if (lo_used || hi_used) {
+      const uint2 v = ld_pair(p + 2 * i);
+      w[2 * i] = v.x, w[2 * i + 1] = v.y;
+    }
   }
 #endif
 }
@@ -251,7 +264,7 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       uint32_t w[NWORD];
-      ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+      ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, w);
 #pragma unroll
       for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, w[dx + PAR]);
     }
@@ -264,7 +277,7 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       uint32_t w[NWORD];
-      ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+      ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, w);
 #pragma unroll
       for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = w[dx + PAR] ^ is0;
     }
@@ -286,12 +299,12 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       if (dy < KEEP) {
-        ld_row<KS>(wp + dy * S::ROW_STRIDE, kept[dy]);
+        ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, kept[dy]);
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, cand[dy][dx] & kept[dy][dx + PAR]);
       } else {
         uint32_t w[NWORD];
-        ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+        ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, w);
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, cand[dy][dx] & w[dx + PAR]);
       }
@@ -313,7 +326,7 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
         for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = bitop3<0x48>(kept[dy][dx + PAR], cand[dy][dx], is0);
       } else {
         uint32_t w[NWORD];
-        ld_row<KS>(wp + dy * S::ROW_STRIDE, w);
+        ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, w);
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = bitop3<0x48>(w[dx + PAR], cand[dy][dx], is0);  // cand & (w ^ is0)
       }
