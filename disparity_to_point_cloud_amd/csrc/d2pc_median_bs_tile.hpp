@@ -51,6 +51,14 @@
 #ifndef D2PC_BS_TRIM_READS
 #define D2PC_BS_TRIM_READS 1
 #endif
+// D2PC_BS_GROUP_ROWS = GR: GR adjacent lanes of the select take GR vertically adjacent output rows of the same columns and visit
+// their window rows by ABSOLUTE row (see select): most of a group's LDS reads are then the same words, served by one bank access.
+// Interleaved on one device (profiles/r06_ab_median_group_rows.txt): PARITY body 578.3 -> 569.8 / 567.0 / 566.2 us for GR = 2 / 4 / 8
+// (shader clock 1.89 -> 1.92 GHz at the same 1,395 W), the bare median kernel 434.5 -> 426.8 / 424.2 / 420.9; the persistent COMPACT body
+// is best at 4 (8 costs it five spilled registers).  1 = rounds 2-5's mapping (lane = (t >> 1) + 4 x row).
+#ifndef D2PC_BS_GROUP_ROWS
+#define D2PC_BS_GROUP_ROWS 4
+#endif
 // D2PC_BS_PRIO = 1 (the product since round 6): the stages AROUND the select (staging, plane words, bytes back, the callers' count /
 // scatter / epilogue stages) run at a raised wave priority (s_setprio 3), the select at the default.  A SIMD arbitrates vector issue
 // between its waves by priority, then age: the few, latency-bound instructions of those stages used to queue behind the co-resident
@@ -240,10 +248,23 @@ __device__ __forceinline__ void ld_row(const uint32_t *p, uint32_t (&w)[2 * Medi
 #endif
 }
 
-template <int KS, int PAR>
-__device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint32_t *__restrict__ bits_out) {
+template <int KS, int PAR, int GR = 1>
+__device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint32_t *__restrict__ bits_out, const uint32_t g = 0u) {
+  // GR > 1 (D2PC_BS_GROUP_ROWS): GR adjacent LANES take GR vertically adjacent output rows of the same columns; `w_row` is the row of the
+  // group's FIRST lane and `g` this lane's place in the group.  The window rows are visited by ABSOLUTE row: slot k holds the row R = k
+  // (mod KS) of the lane's window [g, g + KS) -- row k for the lanes with g <= k, a later one for the others -- so that in most slots all the
+  // lanes of a group ask LDS for the SAME words and one bank access serves them.  The order in which a window's rows are counted does not
+  // matter.  Slots k >= GR - 1 are the same row for every lane; the others' offsets are per-lane registers (GR - 1 of them).
   using S = MedianBsShape<KS>;
   constexpr int NWORD = 2 * S::NREAD;
+  constexpr int NOFF = (GR - 1 < KS ? GR - 1 : KS);   // slots whose row depends on the lane
+  uint32_t off[NOFF > 0 ? NOFF : 1];
+#pragma unroll
+  for (int k = 0; k < NOFF; ++k) {
+    const uint32_t wraps = g > uint32_t(k) ? (g - uint32_t(k) + uint32_t(KS - 1)) / uint32_t(KS) : 0u;   // R = k + KS * ceil((g - k) / KS)
+    off[k] = (uint32_t(k) + uint32_t(KS) * wraps) * uint32_t(S::ROW_STRIDE);
+  }
+  auto row_off = [&](int dy) -> uint32_t { return dy < NOFF ? off[dy] : uint32_t(dy * S::ROW_STRIDE); };
   uint32_t cand[KS][KS];
   // mm = 127 - d as seven words (d = candidates above the median at the start): count + mm >= 128  <=>  count > d  <=>
   // the median's bit is 1; otherwise d becomes d - count, i.e. mm becomes the sum's low seven digits.
@@ -264,7 +285,7 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       uint32_t w[NWORD];
-      ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, w);
+      ld_row<KS, PAR>(wp + row_off(dy), w);
 #pragma unroll
       for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, w[dx + PAR]);
     }
@@ -277,7 +298,7 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       uint32_t w[NWORD];
-      ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, w);
+      ld_row<KS, PAR>(wp + row_off(dy), w);
 #pragma unroll
       for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = w[dx + PAR] ^ is0;
     }
@@ -299,12 +320,12 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       if (dy < KEEP) {
-        ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, kept[dy]);
+        ld_row<KS, PAR>(wp + row_off(dy), kept[dy]);
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, cand[dy][dx] & kept[dy][dx + PAR]);
       } else {
         uint32_t w[NWORD];
-        ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, w);
+        ld_row<KS, PAR>(wp + row_off(dy), w);
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx) csa_add<0>(c, cand[dy][dx] & w[dx + PAR]);
       }
@@ -326,7 +347,7 @@ __device__ __forceinline__ void select(const uint32_t *__restrict__ w_row, uint3
         for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = bitop3<0x48>(kept[dy][dx + PAR], cand[dy][dx], is0);
       } else {
         uint32_t w[NWORD];
-        ld_row<KS, PAR>(wp + dy * S::ROW_STRIDE, w);
+        ld_row<KS, PAR>(wp + row_off(dy), w);
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx) cand[dy][dx] = bitop3<0x48>(w[dx + PAR], cand[dy][dx], is0);  // cand & (w ^ is0)
       }
@@ -515,13 +536,17 @@ __device__ __forceinline__ void median_bs_tile_from(const MedianBsRows<KS> &rows
 
   // ---- 3. the select: wave = one parity of t, 16 rows; lane = (t >> 1) + 4 * row -----------------------
   const uint32_t wave = tid >> 6, lane = tid & 63u;
-  const uint32_t par = wave & 1u, t = 2u * (lane & 3u) + par, row = 16u * (wave >> 1) + (lane >> 2);
+  // lane = place in the row group + GR x (t >> 1) + 4 GR x group: GR = 1 is rounds 2-5's mapping (lane = (t >> 1) + 4 x row)
+  constexpr uint32_t GR = uint32_t(D2PC_BS_GROUP_ROWS);
+  static_assert(GR == 1 || GR == 2 || GR == 4 || GR == 8 || GR == 16, "a wave holds 16 rows of one column parity");
+  const uint32_t par = wave & 1u, g = lane % GR, t = 2u * ((lane / GR) & 3u) + par, row0 = 16u * (wave >> 1) + GR * (lane / (4u * GR));
+  const uint32_t row = row0 + g;
   {
     D2PC_BS_SETPRIO(0);
-    const uint32_t *w_row = s_w + row * uint32_t(S::ROW_STRIDE) + (t - par);
+    const uint32_t *w_row = s_w + row0 * uint32_t(S::ROW_STRIDE) + (t - par);
     uint32_t *bits_out = s_raw + tid;  // the staged bytes are no longer needed
-    if (par) bs::select<KS, 1>(w_row, bits_out);
-    else bs::select<KS, 0>(w_row, bits_out);
+    if (par) bs::select<KS, 1, int(GR)>(w_row, bits_out, g);
+    else bs::select<KS, 0, int(GR)>(w_row, bits_out, g);
     D2PC_BS_SETPRIO(3);
   }
   __syncthreads();  // every wave has finished reading W
